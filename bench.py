@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Horn-Schunck hot path on MI355X: Mpixel*iterations/sec.
+
+One "step" = one pass of the hot path (derivative kernel + `iters` Jacobi sweeps) over one batch
+of `pairs` synthetic image pairs per GPU, frames already resident in HBM, result left in HBM.
+Default workload = BASELINE.json configs[1]: one 1920x1080 translating-texture pair (seed 1),
+lambda 1, 100 iterations, fp32, 1 GPU.  With --gpus N every rank runs the same per-GPU batch on its
+own pairs (independent pairs shard with no collective: "scaling": "weak"); the only communication
+is the barrier + max-over-ranks of the elapsed time.
+
+Launch: python bench.py [--gpus 1]   or, for N > 1,
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+               --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+ALG_BYTES_PER_PX_ITER = 28.0    # read Ix,Iy,It,u,v + write u',v' as fp32 planes
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--pairs", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--lam", type=float, default=1.0)
+    ap.add_argument("--kernel", choices=["auto", "simple", "fused"], default="auto")
+    ap.add_argument("--fuse-steps", type=int, default=0)
+    ap.add_argument("--tile-w", type=int, default=0)
+    ap.add_argument("--tile-h", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0: same as --iters)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run\n" % (args.gpus, world))
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py needs a GPU (the product path has no CPU fallback)\n")
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import opticalflowhs_amd as hs
+    from opticalflowhs_amd import synth
+
+    W, H, iters, pairs = args.width, args.height, args.iters, args.pairs
+    kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED}[args.kernel]
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = hs.HSFlow(W, H, pairs, device=local_rank, stream=stream)
+    frames = []
+    for i in range(pairs):
+        # config C2 uses seed 1; a batch (config C4) uses seed 1000 + global pair index
+        seed = 1 if (pairs == 1 and world == 1) else 1000 + rank * pairs + i
+        A, B = synth.translating_pair(W, H, seed=seed)
+        if i == 0:
+            frames = [A, B]
+        ctx.set_frames(A, B, pair=i)
+
+    p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
+                        fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
+                        threads=args.threads, use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.solve_async(p)
+    torch.cuda.synchronize()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.solve_async(p)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info = ctx.info()
+
+    # Per-kernel durations with HIP events on the launch stream: same K steps again, eager launches
+    # bracketed by hipEventRecord inside the C ABI (params.profile).  Events between launches would
+    # perturb the timed region above, so they run right after it, same process, same buffers.
+    pp = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
+                         fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
+                         threads=args.threads, profile=True)
+    jac_ms = der_ms = 0.0
+    launches = 0
+    nprof = max(1, min(args.steps, 50))
+    for _ in range(nprof):
+        pi = ctx.solve(pp)
+        jac_ms += pi["jacobi_ms"]
+        der_ms += pi["deriv_ms"]
+        launches += pi["jacobi_launches"]
+
+    px = W * H * pairs
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * px * iters * args.steps / elapsed / 1e6
+    avg_launch_ms = jac_ms / max(launches, 1)
+    sweeps_per_launch = iters * nprof / max(launches, 1)
+    alg_bytes_per_launch = ALG_BYTES_PER_PX_ITER * px * sweeps_per_launch
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Mpixel*iterations/sec (Horn-Schunck: derivative pass + Jacobi u/v sweeps, frames resident in HBM)",
+        "value": value, "unit": "Mpix*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, ITER termination"
+                               % (W, H, pairs, args.lam, iters),
+                   "width": W, "height": H, "iters": iters, "pairs_per_gpu": pairs, "lambda": args.lam,
+                   "kernel": {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused"}[info["kernel"]],
+                   "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
+                   "threads": info["threads"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
+                   "hipgraph": not args.no_graph, "sharding": "independent pairs per rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_jacobi_fused" if info["kernel"] == hs.KERNEL_FUSED else "k_jacobi_simple",
+                     "avg_launch_us": avg_launch_ms * 1e3, "sweeps_per_launch": sweeps_per_launch,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                     "note": "achieved = 28 B/pixel/sweep x pixels x sweeps per launch / mean launch time (HIP events); "
+                             "the fused kernel runs several sweeps per launch from LDS, so this can exceed what HBM moves"},
+        "kernel_ms_per_step": {"deriv": der_ms / nprof, "jacobi": jac_ms / nprof, "launches": launches / nprof},
+    }
+
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            if tr.get("width") == W and tr.get("height") == H and tr.get("fuse_steps") == info["fuse_steps"]:
+                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = tr.get("source")
+        except (ValueError, OSError):
+            pass
+
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
+        hs_oracle.build()
+        A, B = frames
+        cit = args.cpu_iters or iters
+        t = time.perf_counter()
+        hs_oracle.calc_optical_flow_hs(A, B, args.lam, cit, term_type=hs_oracle.TERMCRIT_ITER, threads=1)
+        t1 = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": W * H * cit / t1 / 1e6, "unit": "Mpix*iter/s", "cores": 1, "kind": "port",
+                               "sample": "one %dx%d pair, %d iterations, single thread (the original is scalar single-threaded code), %.2f s"
+                                         % (W, H, cit, t1)}
+        nth = hs_oracle.num_threads()
+        t = time.perf_counter()
+        hs_oracle.calc_optical_flow_hs(A, B, args.lam, cit, term_type=hs_oracle.TERMCRIT_ITER, threads=0)
+        t2 = time.perf_counter() - t
+        out["cpu_baseline_all_cores"] = {"value": W * H * cit / t2 / 1e6, "unit": "Mpix*iter/s", "cores": nth, "kind": "port",
+                                         "sample": "same pair, OpenMP row-parallel form, %.2f s" % t2}
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

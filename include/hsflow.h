@@ -1,0 +1,183 @@
+/*
+ * hsflow.h -- C ABI of the MI355X-native Horn-Schunck optical-flow solver (libhsflow.so).
+ *
+ * This is the drop-in boundary for the hot path of miczi/OpticalFlowHS:
+ * everything the reference's HSOpticalFlowOpenCL::setupCL / runDerivatives / runCLKernels /
+ * cleanup did through OpenCL goes through these entry points instead.  Plain pointers and
+ * sizes only; no C++ or torch types.  All planes are single-channel and PLANAR (u8 frames,
+ * fp32 flow) -- not the reference's float4-per-pixel layout (HSOpticalFlowOpenCL.hpp:29-41).
+ *
+ * Reference interfaces replaced, one by one:
+ *   hsflow_create / hsflow_destroy ...... HSOpticalFlowOpenCL::setupCL  (HSOpticalFlowOpenCL.cpp:67-319)
+ *                                          HSOpticalFlowOpenCL::cleanup  (HSOpticalFlowOpenCL.cpp:849-892)
+ *   hsflow_set_frames_u8[_device] ....... clEnqueueWriteBuffer of inputImageBuffer1/2
+ *                                          (HSOpticalFlowOpenCL.cpp:339-357); frames are what
+ *                                          readInputImage produced (:4-44) but kept as u8
+ *   hsflow_solve / hsflow_solve_async ... runDerivatives() + iterations x runCLKernels()
+ *                                          (HSOpticalFlowOpenCL.cpp:321-474, :476-679, loop :749-751)
+ *                                          and, argument for argument, cvCalcOpticalFlowHS
+ *                                          (OpenCV2.1/include/cv.h:481-483) as called at
+ *                                          OpticalFlowOpenCV.cpp:29,94
+ *   hsflow_get_flow[_device] ............ clEnqueueReadBuffer of uBuffer/vBuffer
+ *                                          (HSOpticalFlowOpenCL.cpp:655-675); read at :765-767
+ *   hsflow_get_derivatives .............. clEnqueueReadBuffer of Ex/Ey/Et (:437-468)
+ *   hsflow_calc_optical_flow_hs_8u32f ... one-shot form with the argument list of OpenCV's
+ *                                          icvCalcOpticalFlowHS_8u32fR (cv210.dll VA 0x1012e040)
+ *   status codes ........................ SDK_SUCCESS 0 / SDK_FAILURE 1 (SDKUtil/include/SDKCommon.hpp:23-24)
+ *                                          become 0 / enumerated non-zero
+ *
+ * Threading: a context is single-owner (not thread-safe); one context per (thread, device).
+ * All device work of a context is issued on ONE HIP stream (given at creation, or its own).
+ */
+#ifndef HSFLOW_H_
+#define HSFLOW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSFLOW_VERSION_MAJOR 0
+#define HSFLOW_VERSION_MINOR 1
+
+/* status codes (0 = success, like SDK_SUCCESS) */
+#define HSFLOW_OK 0
+#define HSFLOW_E_ARG 1     /* null pointer / bad enum / bad struct size            */
+#define HSFLOW_E_SIZE 2    /* non-positive size, stride too small or misaligned    */
+#define HSFLOW_E_DEVICE 3  /* a HIP call failed; text in hsflow_last_error         */
+#define HSFLOW_E_OOM 4     /* host or device allocation failed                     */
+#define HSFLOW_E_STATE 5   /* call order (solve before frames were set, ...)       */
+#define HSFLOW_E_NOTERM 6  /* termination rule that would never stop               */
+
+/* termination flags: values of CV_TERMCRIT_ITER / CV_TERMCRIT_EPS (cxtypes.h:894-896) */
+#define HSFLOW_TERM_ITER 1
+#define HSFLOW_TERM_EPS 2
+
+/* discretisation */
+#define HSFLOW_MODE_CV 0      /* cvCalcOpticalFlowHS semantics: Sobel/8 on frame A, 4-neighbour
+                                 mean, lambda (graded parity target)            */
+#define HSFLOW_MODE_CLASSIC 1 /* Kernels.cl semantics: 2x2x2 cube derivatives, 1/6-1/12 mean,
+                                 alpha^2, with the v update restored    */
+
+/* Jacobi kernel selection */
+#define HSFLOW_KERNEL_AUTO 0
+#define HSFLOW_KERNEL_SIMPLE 1 /* one iteration per launch, straight from HBM/L2             */
+#define HSFLOW_KERNEL_FUSED 2  /* `fuse_steps` iterations per launch on an LDS tile with halo */
+
+typedef struct hsflow_ctx hsflow_ctx;
+
+typedef struct hsflow_params {
+    uint32_t struct_size; /* = sizeof(hsflow_params); guards ABI growth                  */
+    int32_t mode;         /* HSFLOW_MODE_*                                               */
+    float lambda;         /* CV mode: Lagrange multiplier of cvCalcOpticalFlowHS         */
+    float alpha;          /* CLASSIC mode: smoothness weight (Kernels.cl:85)             */
+    int32_t term_type;    /* HSFLOW_TERM_ITER | HSFLOW_TERM_EPS                          */
+    int32_t max_iter;     /* CvTermCriteria.max_iter                                     */
+    double epsilon;       /* CvTermCriteria.epsilon (caller rounds through float if it
+                             wants cvTermCriteria()'s behaviour, cxtypes.h:912)          */
+    int32_t use_previous; /* 0: u=v=0 first (reference behaviour); 1: continue from the
+                             flow currently held by the context                          */
+    int32_t kernel;       /* HSFLOW_KERNEL_*                                             */
+    int32_t fuse_steps;   /* FUSED: iterations per launch, 0 = auto                      */
+    int32_t tile_w;       /* FUSED: core tile width  (multiple of 4), 0 = auto           */
+    int32_t tile_h;       /* FUSED: core tile height, 0 = auto                           */
+    int32_t threads;      /* FUSED: workgroup size 256/512/1024, 0 = auto                */
+    int32_t use_graph;    /* 1: capture the launch sequence in a hipGraph and replay it  */
+    int32_t profile;      /* 1: bracket every kernel with HIP events (see hsflow_info)   */
+} hsflow_params;
+
+typedef struct hsflow_info {
+    uint32_t struct_size;
+    int32_t width, height, n_pairs, pitch; /* pitch in elements, same for every plane    */
+    int32_t iterations_done;  /* sweeps executed by the last solve                        */
+    float last_eps;           /* Eps of the last sweep (EPS termination only)             */
+    int32_t kernel;           /* kernel actually used                                     */
+    int32_t fuse_steps, tile_w, tile_h, threads, groups_per_thread;
+    int32_t tiles;            /* workgroups per fused launch                              */
+    int32_t lds_bytes;        /* dynamic LDS per workgroup                                */
+    int32_t jacobi_launches;  /* launches of the Jacobi kernel in the last solve          */
+    float deriv_ms;           /* profile=1: derivative kernel time                        */
+    float jacobi_ms;          /* profile=1: sum of Jacobi kernel times                    */
+    float solve_ms;           /* profile=1: first event to last event of the solve        */
+} hsflow_info;
+
+/* --- lifecycle ---------------------------------------------------------------------------- */
+
+/* Fills p with the defaults (CV mode, lambda 1, ITER|EPS, 100 iterations, eps 1e-6f, auto). */
+void hsflow_default_params(hsflow_params *p);
+
+/* n_pairs independent image pairs of width x height live in one context (n_pairs >= 1).
+ * device: HIP ordinal.  stream: the hipStream_t all work is issued on (e.g. torch's current
+ * stream; NULL is the device's default stream).  own_stream != 0: ignore `stream` and create a
+ * private non-blocking stream instead. */
+int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pairs, void *stream,
+                  int own_stream);
+int hsflow_destroy(hsflow_ctx *ctx); /* NULL is accepted; idempotent per handle */
+
+/* --- frames in ---------------------------------------------------------------------------- */
+
+/* Host u8 single-channel frames, row strides in bytes (>= width).  Synchronous. */
+int hsflow_set_frames_u8(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
+                         const uint8_t *curr, size_t curr_stride);
+/* Same, source already in device memory on ctx's device; enqueued on ctx's stream. */
+int hsflow_set_frames_u8_device(hsflow_ctx *ctx, int pair, const void *d_prev, size_t prev_stride,
+                                const void *d_curr, size_t curr_stride);
+/* Host 8-bit BGR frames (3 bytes/pixel): BGR->gray then optional 3x3 box blur on the GPU, i.e.
+ * the reference CPU route's pre-processing (OpticalFlowOpenCV.cpp:17,20,27-28). Synchronous. */
+int hsflow_set_frames_bgr8(hsflow_ctx *ctx, int pair, const uint8_t *prev_bgr, size_t prev_stride,
+                           const uint8_t *curr_bgr, size_t curr_stride, int blur3x3);
+/* Streaming (camera loop, HSOpticalFlowOpenCL.cpp:810-834): the current frame becomes the
+ * previous one on the device and only the new frame is uploaded. */
+int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t next_stride);
+
+/* --- solve -------------------------------------------------------------------------------- */
+
+/* Derivative pass + Jacobi iterations for every pair of the context.  hsflow_solve returns
+ * after the device finished; hsflow_solve_async only enqueues (ITER-only termination, no
+ * profile) and the caller synchronises the stream or calls hsflow_synchronize. */
+int hsflow_solve(hsflow_ctx *ctx, const hsflow_params *params);
+int hsflow_solve_async(hsflow_ctx *ctx, const hsflow_params *params);
+int hsflow_synchronize(hsflow_ctx *ctx);
+
+/* --- results out -------------------------------------------------------------------------- */
+
+/* fp32 flow to host, row strides in bytes (multiple of 4, >= 4*width).  Synchronous. */
+int hsflow_get_flow(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, float *v, size_t v_stride);
+/* Row range [row0, row0+nrows) of the flow to / from device memory, on ctx's stream (used for
+ * the row-slab halo exchange).  set_ writes into the flow the next
+ * use_previous=1 solve continues from. */
+int hsflow_get_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, void *d_u,
+                           size_t u_stride, void *d_v, size_t v_stride);
+int hsflow_set_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, const void *d_u,
+                           size_t u_stride, const void *d_v, size_t v_stride);
+/* Derivative planes of the last solve as fp32 (CV: Ix, Iy, It; CLASSIC: Ex, Ey, Et). */
+int hsflow_get_derivatives(hsflow_ctx *ctx, int pair, float *dx, float *dy, float *dt,
+                           size_t stride);
+/* The pre-processed u8 frames the solver actually sees (after gray/blur), to host. */
+int hsflow_get_frames_u8(hsflow_ctx *ctx, int pair, uint8_t *prev, size_t prev_stride,
+                         uint8_t *curr, size_t curr_stride);
+
+/* --- introspection ------------------------------------------------------------------------ */
+
+int hsflow_get_info(hsflow_ctx *ctx, hsflow_info *info);
+const char *hsflow_last_error(hsflow_ctx *ctx); /* ctx may be NULL: last create() error */
+const char *hsflow_status_string(int status);
+int hsflow_version(void); /* major*1000 + minor */
+int hsflow_device_count(int *count);
+
+/* --- one-shot ------------------------------------------------------------------------------ */
+
+/* Same argument list as OpenCV's inner routine behind cvCalcOpticalFlowHS: strides in bytes,
+ * term_type/max_iter/epsilon = CvTermCriteria.  Creates a context on device 0, uploads, solves,
+ * downloads, destroys.  use_previous != 0 reads velx/vely as the starting flow. */
+int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, int img_step,
+                                      int width, int height, int use_previous, float *velx,
+                                      float *vely, int vel_step, float lambda, int term_type,
+                                      int max_iter, double epsilon);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSFLOW_H_ */

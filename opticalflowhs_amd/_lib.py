@@ -1,0 +1,101 @@
+"""ctypes binding of libhsflow.so (the C ABI declared in include/hsflow.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent this raises.  The
+product path never touches oracle/.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhsflow.so")
+
+# status codes / enums of include/hsflow.h
+OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
+TERM_ITER, TERM_EPS = 1, 2
+MODE_CV, MODE_CLASSIC = 0, 1
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED = 0, 1, 2
+
+
+class HsflowParams(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("mode", ctypes.c_int32),
+                ("lambda_", ctypes.c_float), ("alpha", ctypes.c_float),
+                ("term_type", ctypes.c_int32), ("max_iter", ctypes.c_int32),
+                ("epsilon", ctypes.c_double), ("use_previous", ctypes.c_int32),
+                ("kernel", ctypes.c_int32), ("fuse_steps", ctypes.c_int32),
+                ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32),
+                ("threads", ctypes.c_int32), ("use_graph", ctypes.c_int32),
+                ("profile", ctypes.c_int32)]
+
+
+class HsflowInfo(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("n_pairs", ctypes.c_int32), ("pitch", ctypes.c_int32),
+                ("iterations_done", ctypes.c_int32), ("last_eps", ctypes.c_float),
+                ("kernel", ctypes.c_int32), ("fuse_steps", ctypes.c_int32),
+                ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32), ("threads", ctypes.c_int32),
+                ("groups_per_thread", ctypes.c_int32), ("tiles", ctypes.c_int32),
+                ("lds_bytes", ctypes.c_int32), ("jacobi_launches", ctypes.c_int32),
+                ("deriv_ms", ctypes.c_float), ("jacobi_ms", ctypes.c_float),
+                ("solve_ms", ctypes.c_float)]
+
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_pp = ctypes.POINTER(HsflowParams)
+
+# name -> (restype, argtypes).  tests/test_abi.py checks this table against include/hsflow.h.
+PROTOTYPES = {
+    "hsflow_default_params": (None, [_pp]),
+    "hsflow_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i]),
+    "hsflow_destroy": (_i, [_vp]),
+    "hsflow_set_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_set_frames_bgr8": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i]),
+    "hsflow_push_frame_u8": (_i, [_vp, _i, _vp, _sz]),
+    "hsflow_solve": (_i, [_vp, _pp]),
+    "hsflow_solve_async": (_i, [_vp, _pp]),
+    "hsflow_synchronize": (_i, [_vp]),
+    "hsflow_get_flow": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_get_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_set_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_get_derivatives": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
+    "hsflow_get_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_get_info": (_i, [_vp, ctypes.POINTER(HsflowInfo)]),
+    "hsflow_last_error": (ctypes.c_char_p, [_vp]),
+    "hsflow_status_string": (ctypes.c_char_p, [_i]),
+    "hsflow_version": (_i, []),
+    "hsflow_device_count": (_i, [ctypes.POINTER(_i)]),
+    "hsflow_calc_optical_flow_hs_8u32f": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i,
+                                               ctypes.c_float, _i, _i, ctypes.c_double]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises ImportError if it cannot be loaded (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "opticalflowhs_amd: %s is missing -- build it with `python -m opticalflowhs_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise ImportError("opticalflowhs_amd: cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("opticalflowhs_amd: %s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HsflowError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "hsflow status %d: %s" % (status, message))
+        self.status = status

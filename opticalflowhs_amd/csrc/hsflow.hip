@@ -1,0 +1,769 @@
+// hsflow.hip -- C ABI (include/hsflow.h) over the HIP kernels in hs_kernels.hip.h.
+//
+// Host side of the hot path, i.e. what HSOpticalFlowOpenCL::setupCL / runDerivatives /
+// runCLKernels / cleanup did with OpenCL (OpticalFlowHS/HSOpticalFlowOpenCL.cpp:67-679,
+// :849-892), re-designed for MI355X: device-resident planar buffers, no per-iteration
+// host<->device copies (the reference moved u,v over PCIe twice per iteration, :483-501 and
+// :655-675), one stream, the whole launch sequence optionally captured as a hipGraph.
+#include "../../include/hsflow.h"
+#include "hs_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxFuse = 32;        // upper bound on sweeps per fused launch
+constexpr int kLdsLimit = 160 * 1024; // bytes of LDS per CU on gfx950
+constexpr int kNumCU = 256;
+
+std::string g_create_error;
+
+struct FusedPlan {
+    hsk::FusedGeom g;
+    int NT, K, lds_bytes, tiles;
+};
+
+struct GraphKey {
+    int mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev;
+    float coeff;
+    bool operator<(const GraphKey &o) const
+    {
+        return std::tie(mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev, coeff) <
+               std::tie(o.mode, o.kernel, o.max_iter, o.T, o.tw, o.th, o.nt, o.lr, o.cur, o.use_prev, o.coeff);
+    }
+};
+
+struct GraphEntry {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int cur_after, launches;
+};
+
+} // namespace
+
+struct hsflow_ctx {
+    int device = 0;
+    int W = 0, H = 0, N = 0, P = 0;
+    long long plane = 0; // elements per pair plane
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *dA = nullptr, *dB = nullptr;
+    uint32_t *dCoef = nullptr;
+    float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
+    unsigned *dEps = nullptr;   // kMaxFuse words
+    unsigned *hEps = nullptr;   // pinned mirror
+    void *dScratch = nullptr;   // staging for colour frames / derivative read-back
+    size_t scratch_bytes = 0;
+    int cur = 0;                // which of dU/dV holds the current flow
+    bool frames_set = false;
+    bool coef_valid = false;
+    hsflow_info info;
+    std::string err;
+    std::map<GraphKey, GraphEntry> graphs;
+    std::vector<hipEvent_t> events;
+    bool capturing = false;
+};
+
+namespace {
+
+int fail(hsflow_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HS_HIP(c, call)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), e_ == hipErrorOutOfMemory ? HSFLOW_E_OOM : HSFLOW_E_DEVICE,          \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+// Tile planner for the fused kernel.  Cost model: the launch takes ceil(tiles / CUs) rounds of
+// one workgroup per CU; a round costs the region area (LDS sweeps dominate) plus a fixed part.
+// ------------------------------------------------------------------------------------------
+bool make_plan(const hsflow_ctx *c, int T, int tw, int th, int nt, FusedPlan &best)
+{
+    const int W = c->W, H = c->H;
+    const int HX = round_up(T, 4);
+    double best_cost = 1e300;
+    bool found = false;
+    const int nts[3] = {1024, 512, 256};
+    for (int nti = 0; nti < 3; nti++) {
+        const int NT = nts[nti];
+        if (nt && nt != NT) continue;
+        const int Kmax = NT == 1024 ? 3 : 4;
+        const int wg_per_cu = 1; // LDS-heavy tiles: plan for one resident workgroup per CU
+        const int cw_lo = tw ? tw : 4, cw_hi = tw ? tw : std::min(round_up(W, 4), 1024);
+        for (int CW = cw_lo; CW <= cw_hi; CW += 4) {
+            const int RW4 = (CW + 2 * HX) / 4;
+            const int ch_lo = th ? th : 1, ch_hi = th ? th : std::min(H, 1024);
+            for (int CH = ch_lo; CH <= ch_hi; CH++) {
+                const int RH = CH + 2 * T;
+                const long long G = (long long)RW4 * RH;
+                if (G > (long long)NT * Kmax) break; // CH only grows
+                const int RS = 4 * RW4 + 8;
+                const long long lds = 2LL * RS * (RH + 2) * 4;
+                if (lds > kLdsLimit) break;
+                const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
+                const long long tiles = (long long)tx * ty * c->N;
+                const int K = (int)((G + NT - 1) / NT);
+                const long long rounds = (tiles + (long long)kNumCU * wg_per_cu - 1) / ((long long)kNumCU * wg_per_cu);
+                // per-round cost ~ K sweeps-worth of work per lane * T, plus load/store of the tile
+                const double per_round = (double)K * NT * 4 * (T + 3.0) + 2000.0;
+                const double cost = (double)rounds * per_round;
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    found = true;
+                    best.NT = NT;
+                    best.K = K;
+                    best.lds_bytes = (int)lds;
+                    best.tiles = (int)tiles;
+                    hsk::FusedGeom &g = best.g;
+                    g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
+                    g.CW = CW; g.CH = CH; g.T = T; g.HX = HX;
+                    g.RW4 = RW4; g.RH = RH; g.RS = RS; g.G = (int)G;
+                    g.tiles_x = tx; g.tiles_y = ty;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+template <int NT, int K, bool EPS, int LR>
+hipError_t launch_fused_t(const hsflow_ctx *c, const FusedPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool configure_only)
+{
+    auto kern = hsk::k_jacobi_fused<NT, K, EPS, LR>;
+    static bool configured[64] = {}; // per instantiation and device: raise the dynamic-LDS cap once
+    if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess; // done ahead of a stream capture
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dCoef, ui, vi, uo,
+                       vo, p.g, coeff, c->dEps);
+    return hipGetLastError();
+}
+
+template <bool EPS, int LR>
+hipError_t launch_fused_e(const hsflow_ctx *c, const FusedPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool cfg)
+{
+#define HS_CASE(NT_, K_)                                                                          \
+    if (p.NT == NT_ && p.K == K_) return launch_fused_t<NT_, K_, EPS, LR>(c, p, ui, vi, uo, vo, coeff, cfg);
+    HS_CASE(1024, 1) HS_CASE(1024, 2) HS_CASE(1024, 3)
+    HS_CASE(512, 1) HS_CASE(512, 2) HS_CASE(512, 3) HS_CASE(512, 4)
+    HS_CASE(256, 1) HS_CASE(256, 2) HS_CASE(256, 3) HS_CASE(256, 4)
+#undef HS_CASE
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int lr, const float *ui,
+                        const float *vi, float *uo, float *vo, float coeff, bool cfg = false)
+{
+    if (eps) return lr ? launch_fused_e<true, 1>(c, p, ui, vi, uo, vo, coeff, cfg)
+                       : launch_fused_e<true, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
+    return lr ? launch_fused_e<false, 1>(c, p, ui, vi, uo, vo, coeff, cfg)
+              : launch_fused_e<false, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
+}
+
+hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const float *vi, float *uo,
+                         float *vo, float coeff)
+{
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    if (eps)
+        hipLaunchKernelGGL(hsk::k_jacobi_simple<true>, grid, block, 0, c->stream, c->dCoef, ui, vi, uo,
+                           vo, c->W, c->H, c->P, c->plane, coeff, c->dEps);
+    else
+        hipLaunchKernelGGL(hsk::k_jacobi_simple<false>, grid, block, 0, c->stream, c->dCoef, ui, vi,
+                           uo, vo, c->W, c->H, c->P, c->plane, coeff, c->dEps);
+    return hipGetLastError();
+}
+
+hipError_t launch_deriv(const hsflow_ctx *c)
+{
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    hipLaunchKernelGGL(hsk::k_deriv_cv, grid, block, 0, c->stream, c->dA, c->dB, c->dCoef, c->W, c->H,
+                       c->P, c->plane);
+    return hipGetLastError();
+}
+
+int check_ctx(hsflow_ctx *c, int pair)
+{
+    if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
+    if (pair < 0 || pair >= c->N) return fail(c, HSFLOW_E_ARG, "pair index out of range");
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HSFLOW_E_DEVICE, "hipSetDevice failed");
+    return HSFLOW_OK;
+}
+
+struct Profiler { // brackets kernels with events when params.profile is set
+    hsflow_ctx *c;
+    bool on;
+    std::vector<std::pair<int, size_t>> marks; // (kind, index of start event); kind 0 deriv, 1 jacobi
+    size_t used = 0;
+    hipEvent_t ev(size_t i)
+    {
+        while (c->events.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            c->events.push_back(e);
+        }
+        return c->events[i];
+    }
+    void begin(int kind)
+    {
+        if (!on) return;
+        marks.push_back({kind, used});
+        hipEventRecord(ev(used), c->stream);
+        used++;
+    }
+    void end()
+    {
+        if (!on) return;
+        hipEventRecord(ev(used), c->stream);
+        used++;
+    }
+    void collect()
+    {
+        if (!on || marks.empty()) return;
+        hipStreamSynchronize(c->stream);
+        float d = 0, j = 0, t = 0;
+        for (auto &m : marks) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, c->events[m.second], c->events[m.second + 1]);
+            (m.first == 0 ? d : j) += ms;
+        }
+        hipEventElapsedTime(&t, c->events[marks.front().second], c->events[used - 1]);
+        c->info.deriv_ms = d;
+        c->info.jacobi_ms = j;
+        c->info.solve_ms = t;
+    }
+};
+
+// Enqueue derivative pass + `iters` Jacobi sweeps (no host synchronisation inside).
+int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters, int kernel, int T,
+                  const FusedPlan *plan, const FusedPlan *tail_plan, int lr, Profiler &prof,
+                  bool do_deriv, bool zero_flow)
+{
+    if (zero_flow) {
+        c->cur = 0;
+        HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+        HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+    }
+    if (do_deriv) {
+        prof.begin(0);
+        HS_HIP(c, launch_deriv(c));
+        prof.end();
+    }
+    int left = iters, launches = 0;
+    while (left > 0) {
+        const int a = c->cur, b = a ^ 1;
+        if (kernel == HSFLOW_KERNEL_SIMPLE) {
+            prof.begin(1);
+            HS_HIP(c, launch_simple(c, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            prof.end();
+            left -= 1;
+        } else {
+            const FusedPlan *pl = (left >= T) ? plan : tail_plan;
+            prof.begin(1);
+            HS_HIP(c, launch_fused(c, *pl, false, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            prof.end();
+            left -= pl->g.T;
+        }
+        c->cur = b;
+        launches++;
+    }
+    c->info.jacobi_launches = launches;
+    (void)p;
+    return HSFLOW_OK;
+}
+
+int pick_T(int max_iter, int requested)
+{
+    if (requested > 0) return std::min(requested, kMaxFuse);
+    // default sweeps per launch; prefer a divisor of max_iter near 8 so that launches are uniform
+    const int pref[] = {8, 10, 7, 9, 6, 12, 5, 4};
+    for (int t : pref)
+        if (max_iter % t == 0) return t;
+    return std::min(8, std::max(1, max_iter));
+}
+
+int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if (!pp || pp->struct_size != sizeof(hsflow_params))
+        return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
+    const hsflow_params &p = *pp;
+    if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
+    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "mode not implemented");
+    const bool use_iter = (p.term_type & HSFLOW_TERM_ITER) != 0, use_eps = (p.term_type & HSFLOW_TERM_EPS) != 0;
+    if (!use_iter && !use_eps) return fail(c, HSFLOW_E_ARG, "term_type must include ITER and/or EPS");
+    if (use_iter && p.max_iter <= 0 && !use_eps)
+        return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+    if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
+    if (async && (use_eps || p.profile))
+        return fail(c, HSFLOW_E_ARG, "solve_async supports ITER-only termination without profiling");
+
+    const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
+    int kernel = p.kernel == HSFLOW_KERNEL_AUTO ? HSFLOW_KERNEL_FUSED : p.kernel;
+    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED)
+        return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
+    const int lr = 1;
+    // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
+    // EPS-only runs use chunks until Eps < epsilon.
+    const long long budget = (use_iter && p.max_iter > 0) ? p.max_iter : (1LL << 40);
+
+    int T = 1;
+    FusedPlan plan{}, tail{};
+    if (kernel == HSFLOW_KERNEL_FUSED) {
+        T = pick_T(budget > (1 << 30) ? 8 : (int)budget, p.fuse_steps);
+        if (budget < T) T = (int)budget;
+        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, plan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the requested tile/threads/fuse_steps");
+        c->info.fuse_steps = T; c->info.tile_w = plan.g.CW; c->info.tile_h = plan.g.CH;
+        c->info.threads = plan.NT; c->info.groups_per_thread = plan.K; c->info.tiles = plan.tiles;
+        c->info.lds_bytes = plan.lds_bytes;
+    } else {
+        c->info.fuse_steps = 1; c->info.tile_w = c->info.tile_h = 0; c->info.threads = 256;
+        c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
+    }
+    c->info.kernel = kernel;
+    c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;
+    c->info.last_eps = 0.f;
+    Profiler prof{c, p.profile != 0};
+
+    if (!use_eps) { // fixed sweep count: nothing on the host between launches
+        const int iters = (int)budget;
+        const int rem = kernel == HSFLOW_KERNEL_FUSED ? iters % T : 0;
+        if (rem && !make_plan(c, rem, p.tile_w, p.tile_h, p.threads, tail))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the tail launch");
+        const bool zero = !p.use_previous;
+        if (p.use_graph && !p.profile) {
+            GraphKey key{p.mode, kernel, iters, T, plan.g.CW, plan.g.CH, plan.NT, lr, zero ? 0 : c->cur,
+                         p.use_previous, coeff};
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                if (kernel == HSFLOW_KERNEL_FUSED) { // function attributes are set outside the capture
+                    HS_HIP(c, launch_fused(c, plan, false, lr, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                    if (rem) HS_HIP(c, launch_fused(c, tail, false, lr, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                }
+                HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int cur0 = c->cur;
+                st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, lr, prof, true, zero);
+                hipGraph_t graph = nullptr;
+                hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
+                if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+                GraphEntry ge{};
+                ge.graph = graph;
+                ge.cur_after = c->cur;
+                ge.launches = c->info.jacobi_launches;
+                HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+                it = c->graphs.emplace(key, ge).first;
+            }
+            HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
+            c->cur = it->second.cur_after;
+            c->info.jacobi_launches = it->second.launches;
+        } else {
+            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, lr, prof, true, zero);
+            if (st) return st;
+        }
+        c->coef_valid = true;
+        c->info.iterations_done = iters;
+        if (!async) {
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            prof.collect();
+        }
+        return HSFLOW_OK;
+    }
+
+    // EPS termination (CvTermCriteria with CV_TERMCRIT_EPS): Eps_k = max |u_k - u_{k-1}|, |v_k - v_{k-1}|
+    // is produced per sweep by the kernel; the host looks at it after every chunk and, if the
+    // threshold was crossed inside the chunk, replays the chunk up to that sweep (its input buffer
+    // is still intact), which reproduces the oracle's stopping sweep exactly.
+    if (!p.use_previous) {
+        c->cur = 0;
+        HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+        HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+    }
+    prof.begin(0);
+    HS_HIP(c, launch_deriv(c));
+    prof.end();
+    c->coef_valid = true;
+    long long done = 0;
+    int launches = 0;
+    float last = 0.f;
+    bool stop = false;
+    while (!stop) {
+        const int chunk = (int)std::min<long long>(T, budget - done);
+        FusedPlan cp = plan;
+        if (kernel == HSFLOW_KERNEL_FUSED && chunk != T && !make_plan(c, chunk, p.tile_w, p.tile_h, p.threads, cp))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for a chunk");
+        const int a = c->cur, b = a ^ 1;
+        HS_HIP(c, hipMemsetAsync(c->dEps, 0, kMaxFuse * sizeof(unsigned), c->stream));
+        prof.begin(1);
+        if (kernel == HSFLOW_KERNEL_SIMPLE)
+            HS_HIP(c, launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+        else
+            HS_HIP(c, launch_fused(c, cp, true, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+        prof.end();
+        launches++;
+        HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEps, kMaxFuse * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        const int n = kernel == HSFLOW_KERNEL_SIMPLE ? 1 : chunk;
+        int hit = -1;
+        for (int s = 0; s < n; s++) {
+            float e;
+            std::memcpy(&e, &c->hEps[s], sizeof(float));
+            last = e;
+            if ((double)e < p.epsilon) { hit = s; break; }
+        }
+        if (hit >= 0 && hit < n - 1) { // crossed inside the chunk: redo exactly hit+1 sweeps
+            FusedPlan rp{};
+            if (!make_plan(c, hit + 1, p.tile_w, p.tile_h, p.threads, rp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the replay");
+            prof.begin(1);
+            HS_HIP(c, launch_fused(c, rp, false, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            prof.end();
+            launches++;
+            done += hit + 1;
+            stop = true;
+        } else {
+            done += n;
+            if (hit >= 0) stop = true;
+        }
+        c->cur = b;
+        if (use_iter && p.max_iter > 0 && done >= budget) stop = true;
+    }
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    c->info.iterations_done = (int)done;
+    c->info.last_eps = last;
+    c->info.jacobi_launches = launches;
+    prof.collect();
+    return HSFLOW_OK;
+}
+
+int copy_frame_in(hsflow_ctx *c, uint8_t *dst, const void *src, size_t stride, hipMemcpyKind kind, bool sync)
+{
+    if (sync) HS_HIP(c, hipMemcpy2D(dst, c->P, src, stride, c->W, c->H, kind));
+    else HS_HIP(c, hipMemcpy2DAsync(dst, c->P, src, stride, c->W, c->H, kind, c->stream));
+    return HSFLOW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void hsflow_default_params(hsflow_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(*p);
+    p->mode = HSFLOW_MODE_CV;
+    p->lambda = 1.0f;
+    p->alpha = 1.0f;
+    p->term_type = HSFLOW_TERM_ITER | HSFLOW_TERM_EPS; // as the reference calls it, OpticalFlowOpenCV.cpp:29
+    p->max_iter = 100;                                  // main.cpp:4
+    p->epsilon = (double)1e-6f;                         // cvTermCriteria rounds through float, cxtypes.h:912
+    p->kernel = HSFLOW_KERNEL_AUTO;
+}
+
+int hsflow_device_count(int *count)
+{
+    if (!count) return HSFLOW_E_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return HSFLOW_E_DEVICE; }
+    *count = n;
+    return HSFLOW_OK;
+}
+
+int hsflow_version(void) { return HSFLOW_VERSION_MAJOR * 1000 + HSFLOW_VERSION_MINOR; }
+
+const char *hsflow_status_string(int s)
+{
+    switch (s) {
+    case HSFLOW_OK: return "ok";
+    case HSFLOW_E_ARG: return "invalid argument";
+    case HSFLOW_E_SIZE: return "invalid size or stride";
+    case HSFLOW_E_DEVICE: return "device error";
+    case HSFLOW_E_OOM: return "out of memory";
+    case HSFLOW_E_STATE: return "invalid call order";
+    case HSFLOW_E_NOTERM: return "termination criteria never met";
+    default: return "unknown status";
+    }
+}
+
+const char *hsflow_last_error(hsflow_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pairs, void *stream, int own_stream)
+{
+    if (!out) return fail(nullptr, HSFLOW_E_ARG, "out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || n_pairs <= 0) return fail(nullptr, HSFLOW_E_SIZE, "width, height, n_pairs must be positive");
+    if ((long long)round_up(width, 64) * height > (1LL << 30)) return fail(nullptr, HSFLOW_E_SIZE, "plane too large (pitch*height > 2^30)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HSFLOW_E_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, HSFLOW_E_ARG, "device ordinal out of range");
+    hsflow_ctx *c = new (std::nothrow) hsflow_ctx();
+    if (!c) return fail(nullptr, HSFLOW_E_OOM, "host allocation failed");
+    c->device = device; c->W = width; c->H = height; c->N = n_pairs;
+    c->P = round_up(width, 64);
+    c->plane = (long long)c->P * height;
+    std::memset(&c->info, 0, sizeof(c->info));
+    c->info.struct_size = sizeof(hsflow_info);
+    c->info.width = width; c->info.height = height; c->info.n_pairs = n_pairs; c->info.pitch = c->P;
+    auto bail = [&](int code, const std::string &m) { g_create_error = m; hsflow_destroy(c); return code; };
+#define HS_TRY(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return bail(e_ == hipErrorOutOfMemory ? HSFLOW_E_OOM : HSFLOW_E_DEVICE,               \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+    HS_TRY(hipSetDevice(device));
+    if (own_stream) {
+        HS_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    } else {
+        c->stream = (hipStream_t)stream;
+    }
+    const size_t px = (size_t)c->plane * n_pairs;
+    HS_TRY(hipMalloc((void **)&c->dA, px));
+    HS_TRY(hipMalloc((void **)&c->dB, px));
+    HS_TRY(hipMalloc((void **)&c->dCoef, px * sizeof(uint32_t)));
+    for (int i = 0; i < 2; i++) {
+        HS_TRY(hipMalloc((void **)&c->dU[i], px * sizeof(float)));
+        HS_TRY(hipMalloc((void **)&c->dV[i], px * sizeof(float)));
+    }
+    HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
+    HS_TRY(hipHostMalloc((void **)&c->hEps, kMaxFuse * sizeof(unsigned), hipHostMallocDefault));
+    // deterministic contents for padding columns and the initial flow
+    HS_TRY(hipMemsetAsync(c->dA, 0, px, c->stream));
+    HS_TRY(hipMemsetAsync(c->dB, 0, px, c->stream));
+    HS_TRY(hipMemsetAsync(c->dCoef, 0, px * sizeof(uint32_t), c->stream));
+    for (int i = 0; i < 2; i++) {
+        HS_TRY(hipMemsetAsync(c->dU[i], 0, px * sizeof(float), c->stream));
+        HS_TRY(hipMemsetAsync(c->dV[i], 0, px * sizeof(float), c->stream));
+    }
+    HS_TRY(hipStreamSynchronize(c->stream));
+#undef HS_TRY
+    *out = c;
+    return HSFLOW_OK;
+}
+
+int hsflow_destroy(hsflow_ctx *c)
+{
+    if (!c) return HSFLOW_OK;
+    hipSetDevice(c->device);
+    if (c->stream || !c->own_stream) hipStreamSynchronize(c->stream);
+    for (auto &kv : c->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
+    hipFree(c->dA); hipFree(c->dB); hipFree(c->dCoef);
+    for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
+    hipFree(c->dEps);
+    if (c->hEps) hipHostFree(c->hEps);
+    hipFree(c->dScratch);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_u8(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if ((st = copy_frame_in(c, c->dA + pair * c->plane, prev, ps, hipMemcpyHostToDevice, true))) return st;
+    if ((st = copy_frame_in(c, c->dB + pair * c->plane, curr, cs, hipMemcpyHostToDevice, true))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_u8_device(hsflow_ctx *c, int pair, const void *dprev, size_t ps, const void *dcurr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!dprev || !dcurr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    if ((st = copy_frame_in(c, c->dA + pair * c->plane, dprev, ps, hipMemcpyDeviceToDevice, false))) return st;
+    if ((st = copy_frame_in(c, c->dB + pair * c->plane, dcurr, cs, hipMemcpyDeviceToDevice, false))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+int hsflow_push_frame_u8(hsflow_ctx *c, int pair, const uint8_t *next, size_t ns)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!next) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ns < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "push_frame needs a previous pair");
+    HS_HIP(c, hipMemcpyAsync(c->dA + pair * c->plane, c->dB + pair * c->plane, (size_t)c->plane, hipMemcpyDeviceToDevice, c->stream));
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if ((st = copy_frame_in(c, c->dB + pair * c->plane, next, ns, hipMemcpyHostToDevice, true))) return st;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_bgr8(hsflow_ctx *c, int, const uint8_t *, size_t, const uint8_t *, size_t, int)
+{
+    return fail(c, HSFLOW_E_ARG, "hsflow_set_frames_bgr8: not implemented yet");
+}
+
+int hsflow_solve(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, false); }
+int hsflow_solve_async(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, true); }
+
+int hsflow_synchronize(hsflow_ctx *c)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    return HSFLOW_OK;
+}
+
+int hsflow_get_flow(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size_t vs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!u || !v) return fail(c, HSFLOW_E_ARG, "null flow pointer");
+    const size_t rowb = (size_t)c->W * 4;
+    if ((us & 3) || (vs & 3) || us < rowb || vs < rowb) return fail(c, HSFLOW_E_SIZE, "flow stride must be a multiple of 4 and >= 4*width");
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    HS_HIP(c, hipMemcpy2D(u, us, c->dU[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
+    HS_HIP(c, hipMemcpy2D(v, vs, c->dV[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
+    return HSFLOW_OK;
+}
+
+static int flow_rows_args(hsflow_ctx *c, int pair, int row0, int nrows, const void *du, size_t us, const void *dv, size_t vs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!du || !dv) return fail(c, HSFLOW_E_ARG, "null flow pointer");
+    if (row0 < 0 || nrows <= 0 || row0 + nrows > c->H) return fail(c, HSFLOW_E_SIZE, "row range outside the frame");
+    const size_t rowb = (size_t)c->W * 4;
+    if ((us & 3) || (vs & 3) || us < rowb || vs < rowb) return fail(c, HSFLOW_E_SIZE, "flow stride must be a multiple of 4 and >= 4*width");
+    return HSFLOW_OK;
+}
+
+int hsflow_get_flow_device(hsflow_ctx *c, int pair, int row0, int nrows, void *du, size_t us, void *dv, size_t vs)
+{
+    int st = flow_rows_args(c, pair, row0, nrows, du, us, dv, vs);
+    if (st) return st;
+    const size_t rowb = (size_t)c->W * 4;
+    const long long off = pair * c->plane + (long long)row0 * c->P;
+    HS_HIP(c, hipMemcpy2DAsync(du, us, c->dU[c->cur] + off, (size_t)c->P * 4, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));
+    HS_HIP(c, hipMemcpy2DAsync(dv, vs, c->dV[c->cur] + off, (size_t)c->P * 4, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));
+    return HSFLOW_OK;
+}
+
+int hsflow_set_flow_device(hsflow_ctx *c, int pair, int row0, int nrows, const void *du, size_t us, const void *dv, size_t vs)
+{
+    int st = flow_rows_args(c, pair, row0, nrows, du, us, dv, vs);
+    if (st) return st;
+    const size_t rowb = (size_t)c->W * 4;
+    const long long off = pair * c->plane + (long long)row0 * c->P;
+    HS_HIP(c, hipMemcpy2DAsync(c->dU[c->cur] + off, (size_t)c->P * 4, du, us, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));
+    HS_HIP(c, hipMemcpy2DAsync(c->dV[c->cur] + off, (size_t)c->P * 4, dv, vs, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));
+    return HSFLOW_OK;
+}
+
+int hsflow_get_derivatives(hsflow_ctx *c, int pair, float *dx, float *dy, float *dt, size_t stride)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!dx || !dy || !dt) return fail(c, HSFLOW_E_ARG, "null derivative pointer");
+    const size_t rowb = (size_t)c->W * 4;
+    if ((stride & 3) || stride < rowb) return fail(c, HSFLOW_E_SIZE, "stride must be a multiple of 4 and >= 4*width");
+    if (!c->coef_valid) return fail(c, HSFLOW_E_STATE, "no derivatives yet: call hsflow_solve first");
+    const size_t need = (size_t)c->W * c->H * 3 * sizeof(float);
+    if (c->scratch_bytes < need) {
+        hipFree(c->dScratch);
+        c->dScratch = nullptr; c->scratch_bytes = 0;
+        HS_HIP(c, hipMalloc(&c->dScratch, need));
+        c->scratch_bytes = need;
+    }
+    float *sx = (float *)c->dScratch, *sy = sx + (size_t)c->W * c->H, *stt = sy + (size_t)c->W * c->H;
+    hipLaunchKernelGGL(hsk::k_unpack_deriv, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,
+                       c->dCoef + pair * c->plane, sx, sy, stt, c->W, c->H, c->P);
+    HS_HIP(c, hipGetLastError());
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    HS_HIP(c, hipMemcpy2D(dx, stride, sx, rowb, rowb, c->H, hipMemcpyDeviceToHost));
+    HS_HIP(c, hipMemcpy2D(dy, stride, sy, rowb, rowb, c->H, hipMemcpyDeviceToHost));
+    HS_HIP(c, hipMemcpy2D(dt, stride, stt, rowb, rowb, c->H, hipMemcpyDeviceToHost));
+    return HSFLOW_OK;
+}
+
+int hsflow_get_frames_u8(hsflow_ctx *c, int pair, uint8_t *prev, size_t ps, uint8_t *curr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    HS_HIP(c, hipMemcpy2D(prev, ps, c->dA + pair * c->plane, c->P, c->W, c->H, hipMemcpyDeviceToHost));
+    HS_HIP(c, hipMemcpy2D(curr, cs, c->dB + pair * c->plane, c->P, c->W, c->H, hipMemcpyDeviceToHost));
+    return HSFLOW_OK;
+}
+
+int hsflow_get_info(hsflow_ctx *c, hsflow_info *info)
+{
+    if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
+    if (!info || info->struct_size != sizeof(hsflow_info)) return fail(c, HSFLOW_E_ARG, "info null or struct_size mismatch");
+    *info = c->info;
+    return HSFLOW_OK;
+}
+
+int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, int img_step, int width, int height,
+                                      int use_previous, float *velx, float *vely, int vel_step, float lambda,
+                                      int term_type, int max_iter, double epsilon)
+{
+    // argument checks of the original, cv210.dll VA 0x1012e089-0x1012e0c7
+    if (!prev || !curr || !velx || !vely) return fail(nullptr, HSFLOW_E_ARG, "null pointer");
+    if (width <= 0 || height <= 0 || width > img_step || (vel_step & 3) || width * 4 > vel_step)
+        return fail(nullptr, HSFLOW_E_SIZE, "bad size or step");
+    hsflow_ctx *c = nullptr;
+    int st = hsflow_create(&c, 0, width, height, 1, nullptr, 1);
+    if (st) return st;
+    hsflow_params p;
+    hsflow_default_params(&p);
+    p.lambda = lambda; p.term_type = term_type; p.max_iter = max_iter; p.epsilon = epsilon;
+    p.use_previous = use_previous ? 1 : 0;
+    st = hsflow_set_frames_u8(c, 0, prev, (size_t)img_step, curr, (size_t)img_step);
+    if (!st && use_previous) { // the caller's velx/vely are the starting flow
+        const size_t rowb = (size_t)width * 4;
+        hipError_t e = hipMemcpy2D(c->dU[c->cur], (size_t)c->P * 4, velx, (size_t)vel_step, rowb, height, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy2D(c->dV[c->cur], (size_t)c->P * 4, vely, (size_t)vel_step, rowb, height, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = HSFLOW_E_DEVICE;
+    }
+    if (!st) st = hsflow_solve(c, &p);
+    if (!st) st = hsflow_get_flow(c, 0, velx, (size_t)vel_step, vely, (size_t)vel_step);
+    if (st) g_create_error = c->err;
+    hsflow_destroy(c);
+    return st;
+}
+
+} // extern "C"

@@ -1,0 +1,86 @@
+"""CPU checks of the drop-in boundary: libhsflow.so loads and exports every symbol that
+include/hsflow.h declares, struct layouts match, and argument errors are reported without a GPU.
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "hsflow.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hsflow_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_tables_agree(hs):
+    names = declared_functions()
+    assert len(names) >= 20
+    assert sorted(hs._lib.PROTOTYPES) == names
+
+
+def test_library_exports_every_declared_symbol(hs):
+    lib = ctypes.CDLL(hs._lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_and_defaults(hs):
+    L = hs._lib.load()
+    p = hs._lib.HsflowParams()
+    L.hsflow_default_params(ctypes.byref(p))
+    assert p.struct_size == ctypes.sizeof(hs._lib.HsflowParams)
+    assert p.mode == hs.MODE_CV and p.term_type == (hs.TERM_ITER | hs.TERM_EPS)
+    assert p.max_iter == 100 and abs(p.epsilon - 1e-6) < 1e-12 and p.lambda_ == 1.0
+    assert L.hsflow_version() >= 1
+    assert L.hsflow_status_string(0) == b"ok"
+    assert L.hsflow_status_string(2) == b"invalid size or stride"
+
+
+def test_argument_errors_without_gpu(hs):
+    L = hs._lib.load()
+    h = ctypes.c_void_p()
+    assert L.hsflow_create(None, 0, 8, 8, 1, None, 1) == hs._lib.E_ARG
+    assert L.hsflow_create(ctypes.byref(h), 0, 0, 8, 1, None, 1) == hs._lib.E_SIZE
+    assert L.hsflow_create(ctypes.byref(h), 0, 8, -1, 1, None, 1) == hs._lib.E_SIZE
+    assert L.hsflow_create(ctypes.byref(h), 0, 8, 8, 0, None, 1) == hs._lib.E_SIZE
+    assert b"positive" in L.hsflow_last_error(None)
+    assert L.hsflow_destroy(None) == 0
+    assert L.hsflow_solve(None, None) == hs._lib.E_ARG
+    assert L.hsflow_get_info(None, None) == hs._lib.E_ARG
+    # one-shot entry: the original's pointer / size checks (cv210.dll VA 0x1012e089-0x1012e0c7)
+    assert L.hsflow_calc_optical_flow_hs_8u32f(None, None, 8, 8, 8, 0, None, None, 32, 1.0, 1, 1, 0.0) == hs._lib.E_ARG
+    buf = (ctypes.c_uint8 * 64)()
+    vel = (ctypes.c_float * 64)()
+    f = L.hsflow_calc_optical_flow_hs_8u32f
+    assert f(buf, buf, 4, 8, 8, 0, vel, vel, 32, 1.0, 1, 1, 0.0) == hs._lib.E_SIZE   # width > img_step
+    assert f(buf, buf, 8, 8, 8, 0, vel, vel, 30, 1.0, 1, 1, 0.0) == hs._lib.E_SIZE   # vel_step % 4
+    assert f(buf, buf, 8, 8, 8, 0, vel, vel, 16, 1.0, 1, 1, 0.0) == hs._lib.E_SIZE   # vel_step < 4*width
+
+
+def test_python_mirror_rejects_bad_types(hs):
+    import numpy as np
+    a = np.zeros((4, 4), np.uint8)
+    f = np.zeros((4, 4), np.float32)
+    with pytest.raises(TypeError):
+        hs.calc_optical_flow_hs(a.astype(np.float32), a, 0, f, f, 1.0, hs.term_criteria(1, 1, 0))
+    with pytest.raises(TypeError):
+        hs.calc_optical_flow_hs(a, a, 0, f.astype(np.float64), f, 1.0, hs.term_criteria(1, 1, 0))
+    with pytest.raises(ValueError):
+        hs.calc_optical_flow_hs(a, a[:2], 0, f, f, 1.0, hs.term_criteria(1, 1, 0))
+    c = hs.term_criteria(3, 50, 1e-6)
+    assert c.epsilon == float(np.float32(1e-6)) and c.max_iter == 50
+
+
+def test_no_oracle_in_product_package():
+    """The product path must not import or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "opticalflowhs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "hs_oracle" not in text and "libhs_oracle" not in text, fn
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn

@@ -1,0 +1,285 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): u and v each within 1e-4 RMS of the oracle on identical u8
+inputs.  The oracle evaluates in double with fp32 stores (x87 semantics of cv210.dll), the GPU in
+pure fp32, so bit equality is not expected between the two; it IS expected between any two GPU
+kernel variants (simple / fused, any tile, any fuse depth, graph or not), which is asserted.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from opticalflowhs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ITER, EPS = 1, 2
+RMS_TOL = 1e-4          # the stated tolerance
+_report = {}
+
+
+def rms(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def check(name, got, want, tol=RMS_TOL):
+    (u, v), (uo, vo) = got, want
+    ru, rv = rms(u, uo), rms(v, vo)
+    mx = float(max(np.abs(u.astype(np.float64) - uo).max(), np.abs(v.astype(np.float64) - vo).max()))
+    _report[name] = {"rms_u": ru, "rms_v": rv, "max_abs": mx, "flow_max": float(max(np.abs(uo).max(), np.abs(vo).max()))}
+    assert np.isfinite(u).all() and np.isfinite(v).all(), name
+    assert ru <= tol and rv <= tol, (name, ru, rv, mx)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def write_report():
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(_report, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def gpu_solve(hs, A, B, lam, it, eps=1e-6, tt=ITER, **kw):
+    H, W = A.shape
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        info = ctx.solve(lam=lam, max_iter=it, epsilon=eps, term_type=tt, **kw)
+        u, v = ctx.flow()
+    return u, v, info
+
+
+def test_native_library_is_loaded(hs, gpu_ok):
+    assert os.path.samefile(hs._lib.load()._name, os.path.join(ROOT, "opticalflowhs_amd", "libhsflow.so"))
+    maps = open("/proc/self/maps").read()
+    assert "libhsflow.so" in maps
+
+
+@pytest.mark.parametrize("shape", [(29, 37), (48, 64), (240, 424), (1, 9), (9, 1), (2, 2), (3, 3), (1, 1), (5, 260), (130, 5)])
+def test_derivatives_bit_exact(hs, oracle, gpu_ok, shape):
+    H, W = shape
+    A, B = synth.random_pair(W, H, seed=H * 31 + W)
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        ctx.solve(lam=1.0, max_iter=1, term_type=ITER)
+        dx, dy, dt = ctx.derivatives()
+        a, b = ctx.frames()
+    Ix, Iy, It = oracle.derivatives(A, B)
+    assert np.array_equal(a, A) and np.array_equal(b, B)
+    assert np.array_equal(dx, Ix) and np.array_equal(dy, Iy) and np.array_equal(dt, It)
+
+
+@pytest.mark.parametrize("shape", [(29, 37), (48, 64), (1, 9), (9, 1), (2, 2), (3, 3), (1, 1), (7, 130), (131, 6)])
+@pytest.mark.parametrize("kernel", ["simple", "fused"])
+def test_small_random_pairs(hs, oracle, gpu_ok, shape, kernel):
+    H, W = shape
+    A, B = synth.random_pair(W, H, seed=H * 131 + W)
+    k = hs.KERNEL_SIMPLE if kernel == "simple" else hs.KERNEL_FUSED
+    for lam in (0.01, 1.0, 10.0):
+        for it in (1, 2, 10, 100):
+            uo, vo = oracle.calc_optical_flow_hs(A, B, lam, it, term_type=ITER)
+            u, v, _ = gpu_solve(hs, A, B, lam, it, kernel=k)
+            check("rand_%dx%d_%s_l%g_i%d" % (W, H, kernel, lam, it), (u, v), (uo, vo))
+
+
+def test_golden_k5(hs, gpu_ok):
+    d = np.load(os.path.join(GOLDEN, "k5_random.npz"))
+    for (W, H) in ((37, 29), (64, 48)):
+        A, B = d["A_%dx%d" % (W, H)], d["B_%dx%d" % (W, H)]
+        for lam in (0.01, 0.1, 1.0, 10.0):
+            for it in (1, 2, 10, 100):
+                u, v, _ = gpu_solve(hs, A, B, lam, it)
+                check("k5_%dx%d_l%g_i%d" % (W, H, lam, it), (u, v),
+                      (d["u_%dx%d_l%g_i%d" % (W, H, lam, it)], d["v_%dx%d_l%g_i%d" % (W, H, lam, it)]))
+
+
+def test_golden_synth_and_bunny(hs, oracle, gpu_ok):
+    d = np.load(os.path.join(GOLDEN, "synth_256x128_s1_l1_i100.npz"))
+    u, v, _ = gpu_solve(hs, d["A"], d["B"], 1.0, 100)
+    check("synth_256x128", (u, v), (d["u"], d["v"]))
+    from PIL import Image  # PGM decoding only
+    fr = [oracle.box_blur3(np.asarray(Image.open(os.path.join(GOLDEN, "bunny_%d_gray.pgm" % i)))) for i in (1, 2)]
+    b = np.load(os.path.join(GOLDEN, "bunny_flow_l1_i50.npz"))
+    # BASELINE config C1: lambda 1, 50 iterations, ITER|EPS with eps 1e-6 as the reference calls it
+    u, v, info = gpu_solve(hs, fr[0], fr[1], 1.0, 50, eps=float(np.float32(1e-6)), tt=ITER | EPS)
+    assert info["iterations_done"] == int(b["iters"]) == 50
+    check("bunny_424x240_l1_i50", (u, v), (b["u"], b["v"]))
+
+
+def test_kernel_variants_are_bit_identical(hs, gpu_ok):
+    A, B = synth.smooth_random_pair(203, 117, seed=4, shift=(1, 1))
+    ref = None
+    variants = [dict(kernel=hs.KERNEL_SIMPLE)]
+    for T in (1, 2, 3, 5, 8, 12):
+        variants.append(dict(kernel=hs.KERNEL_FUSED, fuse_steps=T))
+    variants += [dict(kernel=hs.KERNEL_FUSED, fuse_steps=4, tile_w=32, tile_h=16, threads=256),
+                 dict(kernel=hs.KERNEL_FUSED, fuse_steps=4, tile_w=64, tile_h=24, threads=512),
+                 dict(kernel=hs.KERNEL_FUSED, fuse_steps=6, tile_w=96, tile_h=40, threads=1024),
+                 dict(kernel=hs.KERNEL_FUSED, fuse_steps=7, tile_w=204, tile_h=7),
+                 dict(kernel=hs.KERNEL_FUSED, fuse_steps=5, use_graph=True),
+                 dict(kernel=hs.KERNEL_SIMPLE, use_graph=True)]
+    for kw in variants:
+        u, v, info = gpu_solve(hs, A, B, 0.2, 37, **kw)
+        assert info["iterations_done"] == 37
+        if ref is None:
+            ref = (u, v)
+        else:
+            assert np.array_equal(u, ref[0]) and np.array_equal(v, ref[1]), kw
+
+
+def test_eps_termination_matches_oracle(hs, gpu_ok):
+    d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
+    for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5)):
+        u, v, info = gpu_solve(hs, d["A"], d["B"], 0.002, 500, eps=1e-3, tt=ITER | EPS, **kw)
+        assert abs(info["iterations_done"] - int(d["iters"])) <= 1, info
+        assert info["last_eps"] < 1e-3
+        if info["iterations_done"] == int(d["iters"]):
+            check("eps_stop_%s_%d" % (kw["kernel"], kw.get("fuse_steps", 0)), (u, v), (d["u"], d["v"]))
+    # identical frames: stops after the first sweep with zero flow (K1)
+    A = d["A"]
+    u, v, info = gpu_solve(hs, A, A, 0.1, 100, eps=float(np.float32(1e-6)), tt=ITER | EPS)
+    assert info["iterations_done"] == 1 and not u.any() and not v.any()
+    # EPS only
+    u2, v2, info2 = gpu_solve(hs, d["A"], d["B"], 0.002, 0, eps=1e-3, tt=EPS)
+    assert abs(info2["iterations_done"] - int(d["iters"])) <= 1
+
+
+def test_use_previous_and_row_copies(hs, gpu_ok):
+    import torch
+    A, B = synth.random_pair(70, 33, seed=21)
+    u10, v10, _ = gpu_solve(hs, A, B, 0.3, 10)
+    with hs.HSFlow(70, 33, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        ctx.solve(lam=0.3, max_iter=4, term_type=ITER)
+        ctx.solve(lam=0.3, max_iter=6, term_type=ITER, use_previous=True)
+        u, v = ctx.flow()
+        assert np.array_equal(u, u10) and np.array_equal(v, v10)
+        # device row copies out / in
+        ud = torch.empty((5, 70), dtype=torch.float32, device="cuda")
+        vd = torch.empty((5, 70), dtype=torch.float32, device="cuda")
+        ctx.flow_rows_to(ud, vd, 7, 5)
+        ctx.synchronize()
+        assert np.array_equal(ud.cpu().numpy(), u10[7:12]) and np.array_equal(vd.cpu().numpy(), v10[7:12])
+        zu, ov = torch.zeros_like(ud), torch.ones_like(vd)
+        torch.cuda.synchronize()  # the fills run on torch's stream, the copy on the context's
+        ctx.set_flow_rows_from(zu, ov, 0, 5)
+        ctx.synchronize()
+        u2, v2 = ctx.flow()
+        assert not u2[:5].any() and np.all(v2[:5] == 1) and np.array_equal(u2[5:], u10[5:])
+
+
+def test_batch_of_pairs_and_device_frames(hs, oracle, gpu_ok):
+    import torch
+    W, H, N = 150, 90, 3
+    pairs = [synth.translating_pair(W, H, seed=1000 + i) for i in range(N)]
+    with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+        for i, (A, B) in enumerate(pairs):
+            if i == 1:  # frames already on the device, with a row pitch
+                ta = torch.zeros((H, W + 10), dtype=torch.uint8, device="cuda")
+                tb = torch.zeros((H, W + 10), dtype=torch.uint8, device="cuda")
+                ta[:, :W] = torch.from_numpy(A).cuda()
+                tb[:, :W] = torch.from_numpy(B).cuda()
+                torch.cuda.synchronize()
+                ctx.set_frames(ta[:, :W], tb[:, :W], pair=i)
+            else:
+                ctx.set_frames(A, B, pair=i)
+        ctx.solve(lam=1.0, max_iter=40, term_type=ITER)
+        for i, (A, B) in enumerate(pairs):
+            uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 40, term_type=ITER, threads=0)
+            check("batch%d" % i, ctx.flow(i), (uo, vo))
+            u1, v1, _ = gpu_solve(hs, A, B, 1.0, 40)
+            u, v = ctx.flow(i)
+            assert np.array_equal(u, u1) and np.array_equal(v, v1)
+
+
+def test_strided_host_buffers_and_one_shot(hs, oracle, gpu_ok):
+    import ctypes
+    W, H = 61, 23
+    A, B = synth.random_pair(W, H, seed=5)
+    big_a = np.zeros((H, 80), np.uint8)
+    big_b = np.zeros((H, 80), np.uint8)
+    big_a[:, :W], big_b[:, :W] = A, B
+    velx = np.full((H, 72), 7.0, np.float32)
+    vely = np.full((H, 72), 7.0, np.float32)
+    L = hs._lib.load()
+    st = L.hsflow_calc_optical_flow_hs_8u32f(big_a.ctypes.data, big_b.ctypes.data, 80, W, H, 0, velx.ctypes.data,
+                                             vely.ctypes.data, 72 * 4, 0.5, ITER, 12, 0.0)
+    assert st == 0, L.hsflow_last_error(None)
+    uo, vo = oracle.calc_optical_flow_hs(A, B, 0.5, 12, term_type=ITER)
+    check("one_shot", (velx[:, :W], vely[:, :W]), (uo, vo))
+    assert np.all(velx[:, W:] == 7.0)  # padding untouched
+    # python mirror of cvCalcOpticalFlowHS, with use_previous
+    vx = np.zeros((H, W), np.float32)
+    vy = np.zeros((H, W), np.float32)
+    hs.calc_optical_flow_hs(A, B, 0, vx, vy, 0.5, hs.term_criteria(ITER, 5, 0))
+    hs.calc_optical_flow_hs(A, B, 1, vx, vy, 0.5, hs.term_criteria(ITER, 7, 0))
+    check("mirror_use_previous", (vx, vy), (uo, vo))
+
+
+def test_error_statuses_on_gpu(hs, gpu_ok):
+    A, B = synth.random_pair(16, 8, seed=1)
+    with hs.HSFlow(16, 8, 1, own_stream=True) as ctx:
+        with pytest.raises(hs.HsflowError) as e:
+            ctx.solve(lam=1.0, max_iter=3, term_type=ITER)
+        assert e.value.status == hs._lib.E_STATE
+        ctx.set_frames(A, B)
+        with pytest.raises(hs.HsflowError) as e:
+            ctx.solve(lam=1.0, max_iter=0, term_type=ITER)
+        assert e.value.status == hs._lib.E_NOTERM
+        with pytest.raises(hs.HsflowError) as e:
+            ctx.solve(lam=-1.0, max_iter=3, term_type=ITER)
+        assert e.value.status == hs._lib.E_ARG
+        with pytest.raises(hs.HsflowError):
+            ctx.solve(lam=1.0, max_iter=3, term_type=0)
+        with pytest.raises(hs.HsflowError) as e:
+            ctx.solve(lam=1.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_FUSED, tile_w=4096, tile_h=4096)
+        assert e.value.status == hs._lib.E_SIZE
+        with pytest.raises(ValueError):
+            ctx.set_frames(A[:4], B[:4])
+        with pytest.raises(hs.HsflowError):
+            ctx.flow(pair=3)
+
+
+def test_1080p_full_frame_parity(hs, oracle, gpu_ok):
+    """BASELINE config C2: 1920x1080 translating texture (seed 1), lambda 1, 100 iterations."""
+    A, B = synth.translating_pair(1920, 1080, seed=1)
+    uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 100, term_type=ITER, threads=0)
+    u, v, info = gpu_solve(hs, A, B, 1.0, 100)
+    assert info["kernel"] == hs.KERNEL_FUSED
+    check("c2_1080p_fused", (u, v), (uo, vo))
+    us, vs, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=hs.KERNEL_SIMPLE)
+    assert np.array_equal(u, us) and np.array_equal(v, vs)
+    ug, vg, _ = gpu_solve(hs, A, B, 1.0, 100, use_graph=True)
+    assert np.array_equal(u, ug) and np.array_equal(v, vg)
+
+
+def test_4k_full_frame_parity(hs, oracle, gpu_ok):
+    """BASELINE config C3: 3840x2160 (seed 2), lambda 1, 200 iterations."""
+    A, B = synth.translating_pair(3840, 2160, seed=2)
+    uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 200, term_type=ITER, threads=0)
+    u, v, _ = gpu_solve(hs, A, B, 1.0, 200)
+    check("c3_4k_fused", (u, v), (uo, vo))
+    us, vs, _ = gpu_solve(hs, A, B, 1.0, 200, kernel=hs.KERNEL_SIMPLE)
+    assert np.array_equal(u, us) and np.array_equal(v, vs)
+
+
+def test_large_frame_size_independent_properties(hs, gpu_ok):
+    """Row-slab-sized frame (a 16384-wide strip of config C5): properties that need no oracle.
+    (1) identical frames give exactly zero flow; (2) T fused sweeps == T single sweeps;
+    (3) flipping both frames left-right negates u and mirrors the flow up to rounding."""
+    W, H = 16384, 512
+    A, B = synth.translating_pair(W, H, seed=3)
+    u, v, _ = gpu_solve(hs, A, A, 1.0, 20)
+    assert not u.any() and not v.any()
+    u8, v8, _ = gpu_solve(hs, A, B, 1.0, 24, kernel=hs.KERNEL_FUSED, fuse_steps=8)
+    u1, v1, _ = gpu_solve(hs, A, B, 1.0, 24, kernel=hs.KERNEL_SIMPLE)
+    assert np.array_equal(u8, u1) and np.array_equal(v8, v1)
+    uf, vf, _ = gpu_solve(hs, np.ascontiguousarray(A[:, ::-1]), np.ascontiguousarray(B[:, ::-1]), 1.0, 24)
+    assert rms(uf, -u8[:, ::-1]) < 1e-5 and rms(vf, v8[:, ::-1]) < 1e-5
