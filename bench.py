@@ -74,7 +74,10 @@ def main():
 
     W, H, iters, pairs = args.width, args.height, args.iters, args.pairs
     kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED}[args.kernel]
-    stream = torch.cuda.current_stream().cuda_stream
+    # all work goes to one non-default stream (the legacy default stream cannot be graph-captured)
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     ctx = hs.HSFlow(W, H, pairs, device=local_rank, stream=stream)
     frames = []
     for i in range(pairs):

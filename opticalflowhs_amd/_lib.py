@@ -76,6 +76,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same soname as
+    # /opt/rocm's).  Loading torch first makes libhsflow.so bind to that copy; the other order
+    # would put two runtimes in the process and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "opticalflowhs_amd: %s is missing -- build it with `python -m opticalflowhs_amd.build` "

@@ -356,6 +356,9 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the tail launch");
         const bool zero = !p.use_previous;
         if (p.use_graph && !p.profile) {
+            if (!c->stream)
+                return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
+                                             "context on a non-default stream or with own_stream");
             GraphKey key{p.mode, kernel, iters, T, plan.g.CW, plan.g.CH, plan.NT, lr, zero ? 0 : c->cur,
                          p.use_previous, coeff};
             auto it = c->graphs.find(key);
