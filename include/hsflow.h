@@ -65,6 +65,9 @@ extern "C" {
 #define HSFLOW_KERNEL_AUTO 0
 #define HSFLOW_KERNEL_SIMPLE 1 /* one iteration per launch, straight from HBM/L2             */
 #define HSFLOW_KERNEL_FUSED 2  /* `fuse_steps` iterations per launch on an LDS tile with halo */
+#define HSFLOW_KERNEL_STRIP 3  /* `fuse_steps` iterations per launch on register-resident strips:
+                                  a wavefront holds 256 columns x strip_rows rows in VGPRs, DPP
+                                  for left/right, LDS only for strip-edge rows (AUTO picks this) */
 
 typedef struct hsflow_ctx hsflow_ctx;
 
@@ -83,7 +86,9 @@ typedef struct hsflow_params {
     int32_t fuse_steps;   /* FUSED: iterations per launch, 0 = auto                      */
     int32_t tile_w;       /* FUSED: core tile width  (multiple of 4), 0 = auto           */
     int32_t tile_h;       /* FUSED: core tile height, 0 = auto                           */
-    int32_t threads;      /* FUSED: workgroup size 256/512/1024, 0 = auto                */
+    int32_t threads;      /* FUSED: workgroup size 256/512/1024; STRIP: 64 x wavefronts
+                             per workgroup (64..1024); 0 = auto                          */
+    int32_t strip_rows;   /* STRIP: rows held per lane (1..8), 0 = auto                  */
     int32_t use_graph;    /* 1: capture the launch sequence in a hipGraph and replay it  */
     int32_t profile;      /* 1: bracket every kernel with HIP events (see hsflow_info)   */
 } hsflow_params;

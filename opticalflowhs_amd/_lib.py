@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libhsflow.so")
 OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
 TERM_ITER, TERM_EPS = 1, 2
 MODE_CV, MODE_CLASSIC = 0, 1
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED = 0, 1, 2
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP = 0, 1, 2, 3
 
 
 class HsflowParams(ctypes.Structure):
@@ -23,7 +23,8 @@ class HsflowParams(ctypes.Structure):
                 ("epsilon", ctypes.c_double), ("use_previous", ctypes.c_int32),
                 ("kernel", ctypes.c_int32), ("fuse_steps", ctypes.c_int32),
                 ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32),
-                ("threads", ctypes.c_int32), ("use_graph", ctypes.c_int32),
+                ("threads", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
+                ("use_graph", ctypes.c_int32),
                 ("profile", ctypes.c_int32)]
 
 

@@ -64,6 +64,15 @@ __device__ __forceinline__ void update_cv(float uL, float uR, float uU, float uD
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each with its own
+// 4 MiB L2).  This bijection hands every XCD one CONTIGUOUS range of tiles, so neighbouring tiles
+// -- which re-read each other's halo rows and columns -- share an L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // max over the 64 lanes of a wavefront
 __device__ __forceinline__ float wave_max(float x)
 {
@@ -215,13 +224,14 @@ enum : unsigned { F_ACTIVE = 1u, F_CORE = 2u, F_GU = 4u, F_GD = 8u, F_GL = 16u, 
 // bits [9:8] of the flag word: position pr of image column W-1 inside the group (valid with F_GR)
 
 // GFX9 DPP whole-wavefront shifts by one lane (no LDS traffic): lane l receives lane l-1 / l+1.
-__device__ __forceinline__ float wave_from_prev_lane(float x) // lane 0 keeps its own x
+// bound_ctrl with a zero `old` lets the compiler fold the shift into the consuming VALU instruction.
+__device__ __forceinline__ float wave_from_prev_lane(float x) // lane 0 receives 0
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float wave_from_next_lane(float x) // lane 63 keeps its own x
+__device__ __forceinline__ float wave_from_next_lane(float x) // lane 63 receives 0
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xF, 0xF, true));
 }
 
 // Work decomposition: the region (core tile + halo) is cut into groups of 4 consecutive pixels;
@@ -247,8 +257,9 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
 
     const int tid = threadIdx.x;
     const int tpp = g.tiles_x * g.tiles_y;
-    const int pair = blockIdx.x / tpp;
-    const int t2 = blockIdx.x - pair * tpp;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int pair = tile / tpp;
+    const int t2 = tile - pair * tpp;
     const int by = t2 / g.tiles_x, bx = t2 - by * g.tiles_x;
     const int rx0 = bx * g.CW - g.HX, ry0 = by * g.CH - g.T;
     const long long base = (long long)pair * g.plane;
@@ -372,6 +383,195 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
         if ((fl[k] & (F_ACTIVE | F_CORE)) == (F_ACTIVE | F_CORE)) {
             *(float4 *)(u_out + base + go[k]) = cu[k];
             *(float4 *)(v_out + base + go[k]) = cv[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2, form 3: T Jacobi sweeps per launch on register-resident strips ("strip").
+//
+// A workgroup of NW wavefronts owns a region of 256 columns x (NW*R) rows.  Wavefront w holds rows
+// [w*R, (w+1)*R) entirely in VGPRs: lane l owns the 4 pixels of columns 4l..4l+3 in each of its R
+// rows (u, v and the four coefficients).  Per sweep:
+//   * left/right neighbours come from lanes l-1 / l+1 by DPP wave shifts (the wavefront spans the
+//     whole region width, so there is no seam: lanes 0 and 63 sit on the region edge);
+//   * up/down neighbours inside the strip are the lane's own registers;
+//   * only the strip's first and last row go through LDS (double-buffered, ONE barrier per sweep)
+//     to reach the wavefronts above and below.
+// LDS traffic per sweep is 2 of R rows instead of all of them and nothing is re-read, so the sweep
+// is bound by VALU issue (~13 flops per pixel) rather than by LDS or barriers.
+//
+// Image borders cost nothing inside the sweep loop: Jacobi with a replicate border is exactly
+// Jacobi on the EVEN REFLECTION of the image (u(-1-k) = u(k), same for the coefficients): the
+// mirrored pixel sees the mirrored neighbour set, so the extension stays a reflection sweep after
+// sweep, bit for bit, and pixel 0's left neighbour u(-1) equals u(0) -- the replicate rule.  So the
+// halo outside the image is simply LOADED from mirrored coordinates and then swept like any other
+// pixel; no select, no ghost copy.
+// ------------------------------------------------------------------------------------------
+struct StripGeom {
+    int W, H, P;
+    long long plane;
+    int T, HX;          // sweeps per launch; horizontal halo (multiple of 4, >= T)
+    int CW, CH;         // core = (256 - 2*HX) x (NW*R - 2*T)
+    int NW;             // wavefronts per workgroup
+    int tiles_x, tiles_y;
+};
+
+// index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
+__device__ __forceinline__ int mirror_index(int i, int n)
+{
+    const int p = 2 * n;
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+template <int R, int NTMAX, bool EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
+                                                        const float *__restrict__ u_in,
+                                                        const float *__restrict__ v_in,
+                                                        float *__restrict__ u_out,
+                                                        float *__restrict__ v_out, const StripGeom g,
+                                                        const float ilambda,
+                                                        unsigned *__restrict__ eps_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NW = g.NW;
+    const int tpp = g.tiles_x * g.tiles_y;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int pair = tile / tpp;
+    const int t2 = tile - pair * tpp;
+    const int by = t2 / g.tiles_x, bx = t2 - by * g.tiles_x;
+    const int x0 = bx * g.CW - g.HX + 4 * lane;
+    const int y0 = by * g.CH - g.T + w * R;
+    const long long base = (long long)pair * g.plane;
+    const bool xin = (x0 >= 0) && (x0 + 3 < g.W); // the whole group lies inside the image
+
+    float4 cu[R], cv[R];
+    float cIx[R][4], cIy[R][4], cIt[R][4], cA[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const long long row = base + (long long)mirror_index(y0 + r, g.H) * g.P;
+        uint4 cw;
+        if (xin) {
+            cu[r] = *(const float4 *)(u_in + row + x0);
+            cv[r] = *(const float4 *)(v_in + row + x0);
+            cw = *(const uint4 *)(coef + row + x0);
+        } else { // group straddles or lies outside a side border: reflected columns, one by one
+            const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
+                      xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
+            cu[r] = make_float4(u_in[row + xa], u_in[row + xb], u_in[row + xc], u_in[row + xd]);
+            cv[r] = make_float4(v_in[row + xa], v_in[row + xb], v_in[row + xc], v_in[row + xd]);
+            cw = make_uint4(coef[row + xa], coef[row + xb], coef[row + xc], coef[row + xd]);
+        }
+        const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            unpack_deriv(cc[p], cIx[r][p], cIy[r][p], cIt[r][p]);
+            cA[r][p] = alpha_of(cIx[r][p], cIy[r][p], ilambda);
+        }
+    }
+    // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
+    unsigned rowcore = 0;
+    int rdist[R]; // distance of each row from the core rows (0 inside): wave-uniform
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = w * R + r, y = y0 + r;
+        if (j >= g.T && j < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
+        rdist[r] = j < g.T ? g.T - j : (j >= g.T + g.CH ? j - (g.T + g.CH - 1) : 0);
+    }
+    const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
+    const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
+
+    // One row update.  `up`/`dn` are OLD neighbour rows; writes the new row into cu[r]/cv[r].
+    // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
+    // sweeps skip it (wave-uniform branch), which trims the redundant halo work by about half.
+#define HS_ROW(r, upu, upv, dnu, dnv)                                                              \
+    do {                                                                                           \
+        if (rdist[r] <= g.T - 1 - s) {                                                             \
+            const float4 ou = cu[r], ov = cv[r];                                                   \
+            const float uL = wave_from_prev_lane(ou.w), vL = wave_from_prev_lane(ov.w);            \
+            const float uR = wave_from_next_lane(ou.x), vR = wave_from_next_lane(ov.x);            \
+            float nu[4], nv[4];                                                                    \
+            update_cv(uL, ou.y, upu.x, dnu.x, vL, ov.y, upv.x, dnv.x, cIx[r][0], cIy[r][0], cIt[r][0], cA[r][0], nu[0], nv[0]); \
+            update_cv(ou.x, ou.z, upu.y, dnu.y, ov.x, ov.z, upv.y, dnv.y, cIx[r][1], cIy[r][1], cIt[r][1], cA[r][1], nu[1], nv[1]); \
+            update_cv(ou.y, ou.w, upu.z, dnu.z, ov.y, ov.w, upv.z, dnv.z, cIx[r][2], cIy[r][2], cIt[r][2], cA[r][2], nu[2], nv[2]); \
+            update_cv(ou.z, uR, upu.w, dnu.w, ov.z, vR, upv.w, dnv.w, cIx[r][3], cIy[r][3], cIt[r][3], cA[r][3], nu[3], nv[3]); \
+            if (EPS) {                                                                             \
+                if (((rowcore >> r) & 1u) && lanecore) {                                           \
+                    e = fmaxf(e, fmaxf(fabsf(ou.x - nu[0]), fabsf(ov.x - nv[0])));                 \
+                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ou.y - nu[1]), fabsf(ov.y - nv[1])));    \
+                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ou.z - nu[2]), fabsf(ov.z - nv[2])));    \
+                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ou.w - nu[3]), fabsf(ov.w - nv[3])));    \
+                }                                                                                  \
+            }                                                                                      \
+            cu[r] = make_float4(nu[0], nu[1], nu[2], nu[3]);                                       \
+            cv[r] = make_float4(nv[0], nv[1], nv[2], nv[3]);                                       \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0); /* one row at a time keeps the VGPR pressure down */    \
+    } while (0)
+
+    // Exchange slots: ex[buf][wave][0..3][lane] = {first row u, first row v, last row u, last row v}.
+    // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
+    // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
+    // LDS writes drain while the interior rows are being computed.
+    {
+        float4 *exw = ex + ((size_t)w * 4) * 64 + lane;
+        exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[R - 1]; exw[192] = cv[R - 1];
+    }
+    __syncthreads();
+    const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
+    const int wd = w < NW - 1 ? w + 1 : w, sd = w < NW - 1 ? 0 : 2; // strip below: its first row
+    // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
+#pragma unroll 1
+    for (int s = 0; s < g.T; s++) {
+        const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
+        const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
+        const float4 hu = eu[0], hv = eu[64];   // old row above the strip
+        const float4 du = ed[0], dv = ed[64];   // old row below the strip
+        float e = 0.f;
+        if (R == 1) {
+            HS_ROW(0, hu, hv, du, dv);
+        } else {
+            const float4 o0u = cu[0], o0v = cv[0], oNu = cu[R - 1], oNv = cv[R - 1]; // old edge rows
+            HS_ROW(0, hu, hv, cu[R > 1 ? 1 : 0], cv[R > 1 ? 1 : 0]);
+            if (R == 2) HS_ROW(R - 1, o0u, o0v, du, dv);
+            else HS_ROW(R - 1, cu[R > 2 ? R - 2 : 0], cv[R > 2 ? R - 2 : 0], du, dv);
+            if (s + 1 < g.T) {
+                float4 *exw = ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane;
+                exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[R - 1]; exw[192] = cv[R - 1];
+            }
+            float4 pu = o0u, pv = o0v; // old row r-1 while walking the interior rows downwards
+#pragma unroll
+            for (int r = 1; r < R - 1; r++) {
+                const float4 ku = cu[r], kv = cv[r];
+                if (r + 1 == R - 1) HS_ROW(r, pu, pv, oNu, oNv);
+                else HS_ROW(r, pu, pv, cu[r + 1 < R ? r + 1 : r], cv[r + 1 < R ? r + 1 : r]);
+                pu = ku; pv = kv;
+            }
+        }
+        if (R == 1 && s + 1 < g.T) {
+            float4 *exw = ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane;
+            exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[0]; exw[192] = cv[0];
+        }
+        if (EPS) {
+            e = wave_max(e);
+            if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
+        }
+        if (s + 1 < g.T) __syncthreads();
+    }
+#undef HS_ROW
+
+    if (lanecore) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((rowcore >> r) & 1u) {
+                const long long off = base + (long long)(y0 + r) * g.P + x0;
+                *(float4 *)(u_out + off) = cu[r];
+                *(float4 *)(v_out + off) = cv[r];
+            }
         }
     }
 }

@@ -31,8 +31,21 @@ struct FusedPlan {
     int NT, K, lds_bytes, tiles;
 };
 
+struct StripPlan {
+    hsk::StripGeom g;
+    int R, lds_bytes, tiles;
+};
+
+// A launch plan for T sweeps with either multi-sweep kernel.
+struct JPlan {
+    int kind = 0; // HSFLOW_KERNEL_FUSED or HSFLOW_KERNEL_STRIP
+    int T = 0;
+    FusedPlan f{};
+    StripPlan s{};
+};
+
 struct GraphKey {
-    int mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev;
+    int mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev; // lr: K (fused) or R (strip)
     float coeff;
     bool operator<(const GraphKey &o) const
     {
@@ -183,6 +196,124 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
               : launch_fused_e<false, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Planner for the strip kernel: rows per lane R and wavefronts per workgroup NW.
+// Register budget fixes the wavefronts a SIMD can hold: R <= 4 -> 4, R = 5 -> 3, R <= 8 -> 2.
+// ------------------------------------------------------------------------------------------
+int strip_max_waves(int R) { return R <= 4 ? 16 : (R <= 5 ? 12 : 8); }
+
+bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPlan &best)
+{
+    const int W = c->W, H = c->H;
+    const int HX = round_up(T, 4);
+    const int CW = 256 - 2 * HX;
+    if (CW < 4) return false;
+    double best_cost = 1e300;
+    bool found = false;
+    for (int R = 1; R <= 8; R++) {
+        if (rows && rows != R) continue;
+        const int per_simd = R <= 4 ? 4 : (R <= 5 ? 3 : 2); // wavefronts a SIMD can hold (VGPRs)
+        for (int NW = 1; NW <= strip_max_waves(R); NW++) {
+            if (threads && threads != NW * 64) continue;
+            const int CH = NW * R - 2 * T;
+            if (CH < 1) continue;
+            const int lds = NW * 8192;
+            if (lds > kLdsLimit) continue;
+            const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
+            const long long tiles = (long long)tx * ty * c->N;
+            int wg_per_cu = std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8);
+            if (wg_per_cu < 1) continue;
+            const long long slots = (long long)kNumCU * wg_per_cu;
+            const long long rounds = (tiles + slots - 1) / slots;
+            // waves resident on the busiest SIMD while a round runs
+            const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU);
+            const int wps = (int)((conc * NW + 3) / 4);
+            // cycles: per sweep the busiest SIMD issues wps*R rows of ~115 VALU cycles plus a
+            // barrier/LDS latency; per round the tile is loaded and stored once
+            const double per_round = T * (wps * R * 115.0 + 350.0) + wps * R * 260.0 + 3000.0;
+            const double cost = (double)rounds * per_round;
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                found = true;
+                best.R = R;
+                best.lds_bytes = lds;
+                best.tiles = (int)tiles;
+                hsk::StripGeom &g = best.g;
+                g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
+                g.T = T; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
+                g.tiles_x = tx; g.tiles_y = ty;
+            }
+        }
+    }
+    return found;
+}
+
+template <int R, int NTMAX, bool EPS>
+hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool configure_only)
+{
+    auto kern = hsk::k_jacobi_strip<R, NTMAX, EPS>;
+    static bool configured[64] = {};
+    if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
+                       uo, vo, p.g, coeff, c->dEps);
+    return hipGetLastError();
+}
+
+template <bool EPS>
+hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool cfg)
+{
+    switch (p.R) {
+    case 1: return launch_strip_t<1, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 2: return launch_strip_t<2, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 3: return launch_strip_t<3, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 4: return launch_strip_t<4, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5: return launch_strip_t<5, 768, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 6: return launch_strip_t<6, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 7: return launch_strip_t<7, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 8: return launch_strip_t<8, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)
+{
+    out.kind = kind;
+    out.T = T;
+    if (kind == HSFLOW_KERNEL_STRIP) return make_strip_plan(c, T, p.strip_rows, p.threads, out.s);
+    return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
+}
+
+hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, bool eps, const float *ui, const float *vi,
+                    float *uo, float *vo, float coeff, bool cfg = false)
+{
+    if (pl.kind == HSFLOW_KERNEL_STRIP)
+        return eps ? launch_strip_e<true>(c, pl.s, ui, vi, uo, vo, coeff, cfg)
+                   : launch_strip_e<false>(c, pl.s, ui, vi, uo, vo, coeff, cfg);
+    return launch_fused(c, pl.f, eps, 1, ui, vi, uo, vo, coeff, cfg);
+}
+
+void plan_to_info(hsflow_ctx *c, const JPlan &pl)
+{
+    hsflow_info &i = c->info;
+    i.fuse_steps = pl.T;
+    if (pl.kind == HSFLOW_KERNEL_STRIP) {
+        i.tile_w = pl.s.g.CW; i.tile_h = pl.s.g.CH; i.threads = pl.s.g.NW * 64;
+        i.groups_per_thread = pl.s.R; i.tiles = pl.s.tiles; i.lds_bytes = pl.s.lds_bytes;
+    } else {
+        i.tile_w = pl.f.g.CW; i.tile_h = pl.f.g.CH; i.threads = pl.f.NT;
+        i.groups_per_thread = pl.f.K; i.tiles = pl.f.tiles; i.lds_bytes = pl.f.lds_bytes;
+    }
+}
+
 hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const float *vi, float *uo,
                          float *vo, float coeff)
 {
@@ -258,8 +389,7 @@ struct Profiler { // brackets kernels with events when params.profile is set
 
 // Enqueue derivative pass + `iters` Jacobi sweeps (no host synchronisation inside).
 int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters, int kernel, int T,
-                  const FusedPlan *plan, const FusedPlan *tail_plan, int lr, Profiler &prof,
-                  bool do_deriv, bool zero_flow)
+                  const JPlan *plan, const JPlan *tail_plan, Profiler &prof, bool do_deriv, bool zero_flow)
 {
     if (zero_flow) {
         c->cur = 0;
@@ -280,11 +410,11 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
             prof.end();
             left -= 1;
         } else {
-            const FusedPlan *pl = (left >= T) ? plan : tail_plan;
+            const JPlan *pl = (left >= T) ? plan : tail_plan;
             prof.begin(1);
-            HS_HIP(c, launch_fused(c, *pl, false, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
             prof.end();
-            left -= pl->g.T;
+            left -= pl->T;
         }
         c->cur = b;
         launches++;
@@ -322,24 +452,22 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         return fail(c, HSFLOW_E_ARG, "solve_async supports ITER-only termination without profiling");
 
     const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
-    int kernel = p.kernel == HSFLOW_KERNEL_AUTO ? HSFLOW_KERNEL_FUSED : p.kernel;
-    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED)
+    const int kernel = p.kernel == HSFLOW_KERNEL_AUTO ? HSFLOW_KERNEL_STRIP : p.kernel;
+    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
-    const int lr = 1;
+    const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
     // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
     // EPS-only runs use chunks until Eps < epsilon.
     const long long budget = (use_iter && p.max_iter > 0) ? p.max_iter : (1LL << 40);
 
     int T = 1;
-    FusedPlan plan{}, tail{};
-    if (kernel == HSFLOW_KERNEL_FUSED) {
+    JPlan plan, tail;
+    if (multi) {
         T = pick_T(budget > (1 << 30) ? 8 : (int)budget, p.fuse_steps);
         if (budget < T) T = (int)budget;
-        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, plan))
-            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the requested tile/threads/fuse_steps");
-        c->info.fuse_steps = T; c->info.tile_w = plan.g.CW; c->info.tile_h = plan.g.CH;
-        c->info.threads = plan.NT; c->info.groups_per_thread = plan.K; c->info.tiles = plan.tiles;
-        c->info.lds_bytes = plan.lds_bytes;
+        if (!make_jplan(c, kernel, T, p, plan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the requested tile/threads/rows/fuse_steps");
+        plan_to_info(c, plan);
     } else {
         c->info.fuse_steps = 1; c->info.tile_w = c->info.tile_h = 0; c->info.threads = 256;
         c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
@@ -351,25 +479,25 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
 
     if (!use_eps) { // fixed sweep count: nothing on the host between launches
         const int iters = (int)budget;
-        const int rem = kernel == HSFLOW_KERNEL_FUSED ? iters % T : 0;
-        if (rem && !make_plan(c, rem, p.tile_w, p.tile_h, p.threads, tail))
-            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the tail launch");
+        const int rem = multi ? iters % T : 0;
+        if (rem && !make_jplan(c, kernel, rem, p, tail))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
         const bool zero = !p.use_previous;
         if (p.use_graph && !p.profile) {
             if (!c->stream)
                 return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
                                              "context on a non-default stream or with own_stream");
-            GraphKey key{p.mode, kernel, iters, T, plan.g.CW, plan.g.CH, plan.NT, lr, zero ? 0 : c->cur,
-                         p.use_previous, coeff};
+            GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+                         c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous, coeff};
             auto it = c->graphs.find(key);
             if (it == c->graphs.end()) {
-                if (kernel == HSFLOW_KERNEL_FUSED) { // function attributes are set outside the capture
-                    HS_HIP(c, launch_fused(c, plan, false, lr, nullptr, nullptr, nullptr, nullptr, coeff, true));
-                    if (rem) HS_HIP(c, launch_fused(c, tail, false, lr, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (multi) { // function attributes are set outside the capture
+                    HS_HIP(c, launch_j(c, plan, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                    if (rem) HS_HIP(c, launch_j(c, tail, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 }
                 HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 const int cur0 = c->cur;
-                st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, lr, prof, true, zero);
+                st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, true, zero);
                 hipGraph_t graph = nullptr;
                 hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
@@ -385,7 +513,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             c->cur = it->second.cur_after;
             c->info.jacobi_launches = it->second.launches;
         } else {
-            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, lr, prof, true, zero);
+            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, true, zero);
             if (st) return st;
         }
         c->coef_valid = true;
@@ -416,21 +544,21 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     bool stop = false;
     while (!stop) {
         const int chunk = (int)std::min<long long>(T, budget - done);
-        FusedPlan cp = plan;
-        if (kernel == HSFLOW_KERNEL_FUSED && chunk != T && !make_plan(c, chunk, p.tile_w, p.tile_h, p.threads, cp))
-            return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for a chunk");
+        JPlan cp = plan;
+        if (multi && chunk != T && !make_jplan(c, kernel, chunk, p, cp))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
         const int a = c->cur, b = a ^ 1;
         HS_HIP(c, hipMemsetAsync(c->dEps, 0, kMaxFuse * sizeof(unsigned), c->stream));
         prof.begin(1);
-        if (kernel == HSFLOW_KERNEL_SIMPLE)
+        if (!multi)
             HS_HIP(c, launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
         else
-            HS_HIP(c, launch_fused(c, cp, true, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            HS_HIP(c, launch_j(c, cp, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
         prof.end();
         launches++;
         HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEps, kMaxFuse * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HS_HIP(c, hipStreamSynchronize(c->stream));
-        const int n = kernel == HSFLOW_KERNEL_SIMPLE ? 1 : chunk;
+        const int n = multi ? chunk : 1;
         int hit = -1;
         for (int s = 0; s < n; s++) {
             float e;
@@ -439,11 +567,11 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             if ((double)e < p.epsilon) { hit = s; break; }
         }
         if (hit >= 0 && hit < n - 1) { // crossed inside the chunk: redo exactly hit+1 sweeps
-            FusedPlan rp{};
-            if (!make_plan(c, hit + 1, p.tile_w, p.tile_h, p.threads, rp))
-                return fail(c, HSFLOW_E_SIZE, "no feasible tile plan for the replay");
+            JPlan rp;
+            if (!make_jplan(c, kernel, hit + 1, p, rp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the replay");
             prof.begin(1);
-            HS_HIP(c, launch_fused(c, rp, false, lr, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            HS_HIP(c, launch_j(c, rp, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
             prof.end();
             launches++;
             done += hit + 1;

@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (HsflowError, HsflowInfo, HsflowParams, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE,
+from ._lib import (HsflowError, HsflowInfo, HsflowParams, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP,
                    MODE_CLASSIC, MODE_CV, TERM_EPS, TERM_ITER)
 
 TermCriteria = collections.namedtuple("TermCriteria", "type max_iter epsilon")
@@ -116,7 +116,7 @@ class HSFlow(object):
     # -- solve ---------------------------------------------------------------------------
     def make_params(self, lam=1.0, max_iter=100, epsilon=1e-6, term_type=TERM_ITER | TERM_EPS,
                     use_previous=False, mode=MODE_CV, alpha=1.0, kernel=KERNEL_AUTO, fuse_steps=0,
-                    tile_w=0, tile_h=0, threads=0, use_graph=False, profile=False):
+                    tile_w=0, tile_h=0, threads=0, strip_rows=0, use_graph=False, profile=False):
         p = HsflowParams()
         self._lib.hsflow_default_params(ctypes.byref(p))
         p.mode = mode
@@ -131,6 +131,7 @@ class HSFlow(object):
         p.tile_w = tile_w
         p.tile_h = tile_h
         p.threads = threads
+        p.strip_rows = strip_rows
         p.use_graph = 1 if use_graph else 0
         p.profile = 1 if profile else 0
         return p

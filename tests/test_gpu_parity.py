@@ -77,11 +77,11 @@ def test_derivatives_bit_exact(hs, oracle, gpu_ok, shape):
 
 
 @pytest.mark.parametrize("shape", [(29, 37), (48, 64), (1, 9), (9, 1), (2, 2), (3, 3), (1, 1), (7, 130), (131, 6)])
-@pytest.mark.parametrize("kernel", ["simple", "fused"])
+@pytest.mark.parametrize("kernel", ["simple", "fused", "strip"])
 def test_small_random_pairs(hs, oracle, gpu_ok, shape, kernel):
     H, W = shape
     A, B = synth.random_pair(W, H, seed=H * 131 + W)
-    k = hs.KERNEL_SIMPLE if kernel == "simple" else hs.KERNEL_FUSED
+    k = {"simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP}[kernel]
     for lam in (0.01, 1.0, 10.0):
         for it in (1, 2, 10, 100):
             uo, vo = oracle.calc_optical_flow_hs(A, B, lam, it, term_type=ITER)
@@ -124,6 +124,11 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
                  dict(kernel=hs.KERNEL_FUSED, fuse_steps=6, tile_w=96, tile_h=40, threads=1024),
                  dict(kernel=hs.KERNEL_FUSED, fuse_steps=7, tile_w=204, tile_h=7),
                  dict(kernel=hs.KERNEL_FUSED, fuse_steps=5, use_graph=True),
+                 dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, use_graph=True)]
+    for T, R, nt in ((1, 1, 256), (2, 2, 192), (3, 3, 1024), (4, 4, 1024), (5, 5, 768), (7, 6, 512), (9, 7, 512),
+                     (12, 8, 512), (8, 3, 640), (30, 8, 512), (6, 1, 1024)):
+        variants.append(dict(kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=nt))
+    variants += [
                  dict(kernel=hs.KERNEL_SIMPLE, use_graph=True)]
     for kw in variants:
         u, v, info = gpu_solve(hs, A, B, 0.2, 37, **kw)
@@ -136,7 +141,8 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
 
 def test_eps_termination_matches_oracle(hs, gpu_ok):
     d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
-    for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5)):
+    for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5),
+               dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, fuse_steps=7, strip_rows=2)):
         u, v, info = gpu_solve(hs, d["A"], d["B"], 0.002, 500, eps=1e-3, tt=ITER | EPS, **kw)
         assert abs(info["iterations_done"] - int(d["iters"])) <= 1, info
         assert info["last_eps"] < 1e-3
@@ -241,6 +247,9 @@ def test_error_statuses_on_gpu(hs, gpu_ok):
         with pytest.raises(hs.HsflowError) as e:
             ctx.solve(lam=1.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_FUSED, tile_w=4096, tile_h=4096)
         assert e.value.status == hs._lib.E_SIZE
+        with pytest.raises(hs.HsflowError) as e:  # 2 rows x 1 wavefront cannot hold a 3-sweep halo
+            ctx.solve(lam=1.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_STRIP, strip_rows=2, threads=64)
+        assert e.value.status == hs._lib.E_SIZE
         with pytest.raises(ValueError):
             ctx.set_frames(A[:4], B[:4])
         with pytest.raises(hs.HsflowError):
@@ -252,8 +261,10 @@ def test_1080p_full_frame_parity(hs, oracle, gpu_ok):
     A, B = synth.translating_pair(1920, 1080, seed=1)
     uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 100, term_type=ITER, threads=0)
     u, v, info = gpu_solve(hs, A, B, 1.0, 100)
-    assert info["kernel"] == hs.KERNEL_FUSED
-    check("c2_1080p_fused", (u, v), (uo, vo))
+    assert info["kernel"] == hs.KERNEL_STRIP
+    check("c2_1080p_strip", (u, v), (uo, vo))
+    uf, vf, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=hs.KERNEL_FUSED)
+    assert np.array_equal(u, uf) and np.array_equal(v, vf)
     us, vs, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=hs.KERNEL_SIMPLE)
     assert np.array_equal(u, us) and np.array_equal(v, vs)
     ug, vg, _ = gpu_solve(hs, A, B, 1.0, 100, use_graph=True)
@@ -265,7 +276,7 @@ def test_4k_full_frame_parity(hs, oracle, gpu_ok):
     A, B = synth.translating_pair(3840, 2160, seed=2)
     uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 200, term_type=ITER, threads=0)
     u, v, _ = gpu_solve(hs, A, B, 1.0, 200)
-    check("c3_4k_fused", (u, v), (uo, vo))
+    check("c3_4k_strip", (u, v), (uo, vo))
     us, vs, _ = gpu_solve(hs, A, B, 1.0, 200, kernel=hs.KERNEL_SIMPLE)
     assert np.array_equal(u, us) and np.array_equal(v, vs)
 
@@ -278,7 +289,7 @@ def test_large_frame_size_independent_properties(hs, gpu_ok):
     A, B = synth.translating_pair(W, H, seed=3)
     u, v, _ = gpu_solve(hs, A, A, 1.0, 20)
     assert not u.any() and not v.any()
-    u8, v8, _ = gpu_solve(hs, A, B, 1.0, 24, kernel=hs.KERNEL_FUSED, fuse_steps=8)
+    u8, v8, _ = gpu_solve(hs, A, B, 1.0, 24, kernel=hs.KERNEL_STRIP, fuse_steps=8)
     u1, v1, _ = gpu_solve(hs, A, B, 1.0, 24, kernel=hs.KERNEL_SIMPLE)
     assert np.array_equal(u8, u1) and np.array_equal(v8, v1)
     uf, vf, _ = gpu_solve(hs, np.ascontiguousarray(A[:, ::-1]), np.ascontiguousarray(B[:, ::-1]), 1.0, 24)
