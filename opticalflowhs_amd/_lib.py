@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhsflow.so")
+LIB_PATH = os.environ.get("HSFLOW_LIB_PATH") or os.path.join(HERE, "libhsflow.so")  # override: diagnostic builds
 
 # status codes / enums of include/hsflow.h
 OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)

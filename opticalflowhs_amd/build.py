@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsflow.so")
 SOURCES = ["hsflow.hip"]
 DEPS = ["hsflow.hip", "hs_kernels.hip.h", os.path.join("..", "..", "include", "hsflow.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine",
          "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage"]
 
 

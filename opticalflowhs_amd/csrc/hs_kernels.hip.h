@@ -51,12 +51,21 @@ __device__ __forceinline__ float alpha_of(float Ix, float Iy, float ilambda)
 // One Jacobi update.  Factored form: with p = (Ix*ub + Iy*vb + It)*a,
 // u' = ub - Ix*p and v' = vb - Iy*p, which equals ub - (Ix^2*ub + Ix*Iy*vb + Ix*It)*a in exact
 // arithmetic (the oracle's record products are exact).
+//
+// Canonical order of the 4-neighbour sum (every kernel uses it, so all variants agree bit for bit):
+//   even image column:  ((R + (U + D)) + L) * 0.25      odd column:  ((L + (U + D)) + R) * 0.25
+// This is what the packed-fp32 strip kernel computes without any register shuffles, and it is
+// symmetric under the even reflection x -> -1-x (parity and the roles of L and R flip together),
+// which the reflection halo of the strip kernel needs.
+template <int ODD>
 __device__ __forceinline__ void update_cv(float uL, float uR, float uU, float uD, float vL,
                                           float vR, float vU, float vD, float Ix, float Iy,
                                           float It, float a, float &un, float &vn)
 {
-    const float ub = ((uL + uR) + (uU + uD)) * 0.25f;
-    const float vb = ((vL + vR) + (vU + vD)) * 0.25f;
+    const float su = ODD ? ((uL + (uU + uD)) + uR) : ((uR + (uU + uD)) + uL);
+    const float sv = ODD ? ((vL + (vU + vD)) + vR) : ((vR + (vU + vD)) + vL);
+    const float ub = su * 0.25f;
+    const float vb = sv * 0.25f;
     const float p = __fmaf_rn(Ix, ub, __fmaf_rn(Iy, vb, It)) * a;
     un = __fmaf_rn(-Ix, p, ub);
     vn = __fmaf_rn(-Iy, p, vb);
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
             // replicate border: the last image column is its own right neighbour
             const bool last = (x0 + k >= W - 1);
             const float uR = last ? wu[k + 1] : wu[k + 2], vR = last ? wv[k + 1] : wv[k + 2];
-            update_cv(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], Ix, Iy, It, a, nu[k], nv[k]);
+            if (k & 1) update_cv<1>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], Ix, Iy, It, a, nu[k], nv[k]);
+            else update_cv<0>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], Ix, Iy, It, a, nu[k], nv[k]);
             if (EPS && x0 + k < W)
                 e = fmaxf(e, fmaxf(fabsf(wu[k + 1] - nu[k]), fabsf(wv[k + 1] - nv[k])));
         }
@@ -342,10 +352,10 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                 if (f & F_GL) { uL = cu[k].x; vL = cv[k].x; }        // replicate: column 0 is its own left
                 if (pr == 3) { uR = cu[k].w; vR = cv[k].w; }          // replicate: column W-1 is its own right
                 float nu[4], nv[4];
-                update_cv(uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cIx[k][0], cIy[k][0], cIt[k][0], cA[k][0], nu[0], nv[0]);
-                update_cv(cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cIx[k][1], cIy[k][1], cIt[k][1], cA[k][1], nu[1], nv[1]);
-                update_cv(cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cIx[k][2], cIy[k][2], cIt[k][2], cA[k][2], nu[2], nv[2]);
-                update_cv(cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cIx[k][3], cIy[k][3], cIt[k][3], cA[k][3], nu[3], nv[3]);
+                update_cv<0>(uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cIx[k][0], cIy[k][0], cIt[k][0], cA[k][0], nu[0], nv[0]);
+                update_cv<1>(cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cIx[k][1], cIy[k][1], cIt[k][1], cA[k][1], nu[1], nv[1]);
+                update_cv<0>(cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cIx[k][2], cIy[k][2], cIt[k][2], cA[k][2], nu[2], nv[2]);
+                update_cv<1>(cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cIx[k][3], cIy[k][3], cIt[k][3], cA[k][3], nu[3], nv[3]);
                 if (EPS && (f & F_CORE)) { // columns > pr lie outside the image
                     e = fmaxf(e, fmaxf(fabsf(cu[k].x - nu[0]), fabsf(cv[k].x - nv[0])));
                     if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(cu[k].y - nu[1]), fabsf(cv[k].y - nv[1])));
@@ -420,10 +430,55 @@ struct StripGeom {
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
 __device__ __forceinline__ int mirror_index(int i, int n)
 {
-    const int p = 2 * n;
-    int m = i % p;
-    if (m < 0) m += p;
-    return m < n ? m : p - 1 - m;
+    if (i < 0) i = -1 - i;            // one bounce covers every image at least as large as the halo
+    if (i >= n) i = 2 * n - 1 - i;
+    if ((unsigned)i >= (unsigned)n) { // tiny image: general even-periodic extension
+        const int p = 2 * n;
+        int m = i % p;
+        if (m < 0) m += p;
+        i = m < n ? m : p - 1 - m;
+    }
+    return i;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs, so that every
+// arithmetic step except the four side-neighbour additions is a packed (2 pixels per
+// instruction) v_pk_add/mul/fma_f32.  Summation order = the canonical one of update_cv<>:
+//   p0: ((p1 + (U+D)) + left)   p1: ((p0 + (U+D)) + p2)   p2: ((p3 + (U+D)) + p1)   p3: ((p2 + (U+D)) + right)
+struct RowCoef { f2 IxP, IxQ, IyP, IyQ, ItP, ItQ, aP, aQ; };
+
+__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const f2 upuP, const f2 upuQ,
+                                                 const f2 upvP, const f2 upvQ, const f2 dnuP, const f2 dnuQ,
+                                                 const f2 dnvP, const f2 dnvQ, const RowCoef &c)
+{
+    // u plane
+    f2 tP = f2_swap(uP) + (upuP + dnuP);
+    f2 tQ = f2_swap(uQ) + (upuQ + dnuQ);
+    tP.x += wave_from_prev_lane(uQ.y);
+    tP.y += uQ.x;
+    tQ.x += uP.y;
+    tQ.y += wave_from_next_lane(uP.x);
+    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f;
+    // v plane
+    f2 sP = f2_swap(vP) + (upvP + dnvP);
+    f2 sQ = f2_swap(vQ) + (upvQ + dnvQ);
+    sP.x += wave_from_prev_lane(vQ.y);
+    sP.y += vQ.x;
+    sQ.x += vP.y;
+    sQ.y += wave_from_next_lane(vP.x);
+    const f2 vbP = sP * 0.25f, vbQ = sQ * 0.25f;
+    // update
+    const f2 pP = f2_fma(c.IxP, ubP, f2_fma(c.IyP, vbP, c.ItP)) * c.aP;
+    const f2 pQ = f2_fma(c.IxQ, ubQ, f2_fma(c.IyQ, vbQ, c.ItQ)) * c.aQ;
+    uP = f2_fma(-c.IxP, pP, ubP);
+    vP = f2_fma(-c.IyP, pP, vbP);
+    uQ = f2_fma(-c.IxQ, pQ, ubQ);
+    vQ = f2_fma(-c.IyQ, pQ, vbQ);
 }
 
 template <int R, int NTMAX, bool EPS>
@@ -433,9 +488,15 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         float *__restrict__ u_out,
                                                         float *__restrict__ v_out, const StripGeom g,
                                                         const float ilambda,
-                                                        unsigned *__restrict__ eps_out)
+                                                        unsigned *__restrict__ eps_out,
+                                                        unsigned long long *__restrict__ stamps)
 {
+    // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
+    // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
+    // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hsflow.hip).
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64]
+    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
+    if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = g.NW;
@@ -449,29 +510,74 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     const long long base = (long long)pair * g.plane;
     const bool xin = (x0 >= 0) && (x0 + 3 < g.W); // the whole group lies inside the image
 
-    float4 cu[R], cv[R];
-    float cIx[R][4], cIy[R][4], cIt[R][4], cA[R][4];
+    f2 uP[R], uQ[R], vP[R], vQ[R];
+    RowCoef cf[R];
+    float4 lu[R], lv[R];
+    uint4 lc[R];
+    // Workgroup-uniform: does the region (core + halo) stick out of the image on the left or right?
+    // Tiles that do not (the vast majority) load with plain aligned 16-byte accesses only.
+    const int rx0 = bx * g.CW - g.HX;
+    if (rx0 >= 0 && rx0 + 256 <= g.W) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long long off = base + (long long)mirror_index(y0 + r, g.H) * g.P + x0;
+            lu[r] = *(const float4 *)(u_in + off);
+            lv[r] = *(const float4 *)(v_in + off);
+            lc[r] = *(const uint4 *)(coef + off);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long long row = base + (long long)mirror_index(y0 + r, g.H) * g.P;
+            // A group that lies completely outside the image on the left mirrors onto an aligned
+            // group read backwards (columns -1-k <-> k); the same holds on the right when W % 4 == 0.
+            // Those lanes keep the 16-byte loads (from the mirrored address, components reversed).
+            // Only groups that straddle column W-1 or sit right of it when W % 4 != 0 (and images
+            // narrower than the halo) fall back to four reflected scalar loads per plane.
+            int xg = x0;
+            bool rev = false, slow = false;
+            if (!xin) {
+                if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; rev = true; }
+                else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
+                else { xg = 0; slow = true; }
+            }
+            float4 a = *(const float4 *)(u_in + row + xg);
+            float4 b = *(const float4 *)(v_in + row + xg);
+            uint4 c = *(const uint4 *)(coef + row + xg);
+            if (rev) {
+                a = make_float4(a.w, a.z, a.y, a.x);
+                b = make_float4(b.w, b.z, b.y, b.x);
+                c = make_uint4(c.w, c.z, c.y, c.x);
+            }
+            if (slow) { // volatile keeps this a separate, rarely taken path
+                const volatile float *uv = u_in + row, *vv = v_in + row;
+                const volatile uint32_t *cv = coef + row;
+                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
+                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
+                a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+            }
+            lu[r] = a; lv[r] = b; lc[r] = c;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const long long row = base + (long long)mirror_index(y0 + r, g.H) * g.P;
-        uint4 cw;
-        if (xin) {
-            cu[r] = *(const float4 *)(u_in + row + x0);
-            cv[r] = *(const float4 *)(v_in + row + x0);
-            cw = *(const uint4 *)(coef + row + x0);
-        } else { // group straddles or lies outside a side border: reflected columns, one by one
-            const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
-                      xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-            cu[r] = make_float4(u_in[row + xa], u_in[row + xb], u_in[row + xc], u_in[row + xd]);
-            cv[r] = make_float4(v_in[row + xa], v_in[row + xb], v_in[row + xc], v_in[row + xd]);
-            cw = make_uint4(coef[row + xa], coef[row + xb], coef[row + xc], coef[row + xd]);
-        }
+        const float4 lu_ = lu[r], lv_ = lv[r];
+        const uint4 cw = lc[r];
+        uP[r] = f2{lu_.x, lu_.y}; uQ[r] = f2{lu_.z, lu_.w};
+        vP[r] = f2{lv_.x, lv_.y}; vQ[r] = f2{lv_.z, lv_.w};
+        float Ix[4], Iy[4], It[4], a[4];
         const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            unpack_deriv(cc[p], cIx[r][p], cIy[r][p], cIt[r][p]);
-            cA[r][p] = alpha_of(cIx[r][p], cIy[r][p], ilambda);
+            unpack_deriv(cc[p], Ix[p], Iy[p], It[p]);
+            a[p] = alpha_of(Ix[p], Iy[p], ilambda);
         }
+        cf[r].IxP = f2{Ix[0], Ix[1]}; cf[r].IxQ = f2{Ix[2], Ix[3]};
+        cf[r].IyP = f2{Iy[0], Iy[1]}; cf[r].IyQ = f2{Iy[2], Iy[3]};
+        cf[r].ItP = f2{It[0], It[1]}; cf[r].ItQ = f2{It[2], It[3]};
+        cf[r].aP = f2{a[0], a[1]};    cf[r].aQ = f2{a[2], a[3]};
     }
     // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
     unsigned rowcore = 0;
@@ -485,94 +591,115 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
 
-    // One row update.  `up`/`dn` are OLD neighbour rows; writes the new row into cu[r]/cv[r].
+    // One row update.  up*/dn* are OLD neighbour rows; the new row replaces uP[r].. in place.
     // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
     // sweeps skip it (wave-uniform branch), which trims the redundant halo work by about half.
-#define HS_ROW(r, upu, upv, dnu, dnv)                                                              \
+#ifdef HS_DIAG_NO_COMPUTE /* diagnostic build only: wrong results, times the exchange alone */
+#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ) do { uP[r] += UUP + DUP; } while (0)
+#else
+#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
     do {                                                                                           \
         if (rdist[r] <= g.T - 1 - s) {                                                             \
-            const float4 ou = cu[r], ov = cv[r];                                                   \
-            const float uL = wave_from_prev_lane(ou.w), vL = wave_from_prev_lane(ov.w);            \
-            const float uR = wave_from_next_lane(ou.x), vR = wave_from_next_lane(ov.x);            \
-            float nu[4], nv[4];                                                                    \
-            update_cv(uL, ou.y, upu.x, dnu.x, vL, ov.y, upv.x, dnv.x, cIx[r][0], cIy[r][0], cIt[r][0], cA[r][0], nu[0], nv[0]); \
-            update_cv(ou.x, ou.z, upu.y, dnu.y, ov.x, ov.z, upv.y, dnv.y, cIx[r][1], cIy[r][1], cIt[r][1], cA[r][1], nu[1], nv[1]); \
-            update_cv(ou.y, ou.w, upu.z, dnu.z, ov.y, ov.w, upv.z, dnv.z, cIx[r][2], cIy[r][2], cIt[r][2], cA[r][2], nu[2], nv[2]); \
-            update_cv(ou.z, uR, upu.w, dnu.w, ov.z, vR, upv.w, dnv.w, cIx[r][3], cIy[r][3], cIt[r][3], cA[r][3], nu[3], nv[3]); \
+            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
+            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
             if (EPS) {                                                                             \
                 if (((rowcore >> r) & 1u) && lanecore) {                                           \
-                    e = fmaxf(e, fmaxf(fabsf(ou.x - nu[0]), fabsf(ov.x - nv[0])));                 \
-                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ou.y - nu[1]), fabsf(ov.y - nv[1])));    \
-                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ou.z - nu[2]), fabsf(ov.z - nv[2])));    \
-                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ou.w - nu[3]), fabsf(ov.w - nv[3])));    \
+                    e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
+                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
+                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ouQ.x - uQ[r].x), fabsf(ovQ.x - vQ[r].x))); \
+                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ouQ.y - uQ[r].y), fabsf(ovQ.y - vQ[r].y))); \
                 }                                                                                  \
             }                                                                                      \
-            cu[r] = make_float4(nu[0], nu[1], nu[2], nu[3]);                                       \
-            cv[r] = make_float4(nv[0], nv[1], nv[2], nv[3]);                                       \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0); /* one row at a time keeps the VGPR pressure down */    \
     } while (0)
+#endif
+#ifdef HS_DIAG_NO_EXCHANGE /* diagnostic build only: wrong results, times the VALU part alone */
+#define HS_PUBLISH(buf) do { } while (0)
+#else
+#define HS_PUBLISH(buf)                                                                            \
+    do {                                                                                           \
+        float4 *exw = ex + ((size_t)((buf) * NW + w) * 4) * 64 + lane;                             \
+        exw[0] = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y);                                  \
+        exw[64] = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);                                 \
+        exw[128] = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y);                \
+        exw[192] = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);                \
+    } while (0)
+#endif
 
     // Exchange slots: ex[buf][wave][0..3][lane] = {first row u, first row v, last row u, last row v}.
     // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
     // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
     // LDS writes drain while the interior rows are being computed.
-    {
-        float4 *exw = ex + ((size_t)w * 4) * 64 + lane;
-        exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[R - 1]; exw[192] = cv[R - 1];
-    }
+    HS_PUBLISH(0);
     __syncthreads();
+    if (stamps) st1 = __builtin_amdgcn_s_memtime();
     const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
     const int wd = w < NW - 1 ? w + 1 : w, sd = w < NW - 1 ? 0 : 2; // strip below: its first row
     // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
 #pragma unroll 1
     for (int s = 0; s < g.T; s++) {
+#ifdef HS_DIAG_NO_EXCHANGE
+        const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
+#else
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
         const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
-        const float4 hu = eu[0], hv = eu[64];   // old row above the strip
-        const float4 du = ed[0], dv = ed[64];   // old row below the strip
+        const float4 hu4 = eu[0], hv4 = eu[64];   // old row above the strip
+        const float4 du4 = ed[0], dv4 = ed[64];   // old row below the strip
+#endif
+        const f2 huP = f2{hu4.x, hu4.y}, huQ = f2{hu4.z, hu4.w}, hvP = f2{hv4.x, hv4.y}, hvQ = f2{hv4.z, hv4.w};
+        const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
         float e = 0.f;
         if (R == 1) {
-            HS_ROW(0, hu, hv, du, dv);
+            HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ);
         } else {
-            const float4 o0u = cu[0], o0v = cv[0], oNu = cu[R - 1], oNv = cv[R - 1]; // old edge rows
-            HS_ROW(0, hu, hv, cu[R > 1 ? 1 : 0], cv[R > 1 ? 1 : 0]);
-            if (R == 2) HS_ROW(R - 1, o0u, o0v, du, dv);
-            else HS_ROW(R - 1, cu[R > 2 ? R - 2 : 0], cv[R > 2 ? R - 2 : 0], du, dv);
-            if (s + 1 < g.T) {
-                float4 *exw = ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane;
-                exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[R - 1]; exw[192] = cv[R - 1];
-            }
-            float4 pu = o0u, pv = o0v; // old row r-1 while walking the interior rows downwards
+            constexpr int R1 = R > 1 ? 1 : 0, RM = R > 2 ? R - 2 : 0;
+            const f2 o0uP = uP[0], o0uQ = uQ[0], o0vP = vP[0], o0vQ = vQ[0];                 // old first row
+            const f2 oNuP = uP[R - 1], oNuQ = uQ[R - 1], oNvP = vP[R - 1], oNvQ = vQ[R - 1]; // old last row
+            HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1]);
+            if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ);
+            else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ);
+            if (s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+            f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
-                const float4 ku = cu[r], kv = cv[r];
-                if (r + 1 == R - 1) HS_ROW(r, pu, pv, oNu, oNv);
-                else HS_ROW(r, pu, pv, cu[r + 1 < R ? r + 1 : r], cv[r + 1 < R ? r + 1 : r]);
-                pu = ku; pv = kv;
+                const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
+                const int rn = r + 1 < R ? r + 1 : r;
+                if (r + 1 == R - 1) HS_ROW(r, puP, puQ, pvP, pvQ, oNuP, oNuQ, oNvP, oNvQ);
+                else HS_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
+                puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
             }
         }
-        if (R == 1 && s + 1 < g.T) {
-            float4 *exw = ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane;
-            exw[0] = cu[0]; exw[64] = cv[0]; exw[128] = cu[0]; exw[192] = cv[0];
-        }
+        if (R == 1 && s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
         if (EPS) {
             e = wave_max(e);
             if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
         }
+#ifndef HS_DIAG_NO_EXCHANGE
         if (s + 1 < g.T) __syncthreads();
+#endif
     }
 #undef HS_ROW
+#undef HS_PUBLISH
+    if (stamps) st2 = __builtin_amdgcn_s_memtime();
 
     if (lanecore) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((rowcore >> r) & 1u) {
                 const long long off = base + (long long)(y0 + r) * g.P + x0;
-                *(float4 *)(u_out + off) = cu[r];
-                *(float4 *)(v_out + off) = cv[r];
+                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
             }
         }
+    }
+    if (stamps && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0); // stores issued and acknowledged
+        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); // XCC_ID
+        o[7] = (unsigned long long)tile;
     }
 }
 

@@ -71,6 +71,7 @@ struct hsflow_ctx {
     uint8_t *dA = nullptr, *dB = nullptr;
     uint32_t *dCoef = nullptr;
     float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
+    unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
     unsigned *dEps = nullptr;   // kMaxFuse words
     unsigned *hEps = nullptr;   // pinned mirror
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
@@ -203,7 +204,28 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 // ------------------------------------------------------------------------------------------
 int strip_max_waves(int R) { return R <= 4 ? 16 : (R <= 5 ? 12 : 8); }
 
-bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPlan &best)
+// Cost model (shader cycles at ~2.2 GHz), fitted to in-kernel phase stamps on MI355X at 1080p
+// (tools/stamps.py; profiles/): one launch = fixed launch/drain gap + per round [tile load +
+// T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
+double strip_launch_cost(int T, int R, int NW, long long tiles, int *wg_per_cu_out = nullptr)
+{
+    const int per_simd = R <= 4 ? 4 : (R <= 5 ? 3 : 2);
+    const int lds = NW * 8192;
+    const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
+    if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
+    const long long slots = (long long)kNumCU * wg_per_cu;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // WGs sharing a CU
+    const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
+    const double row_cycles = wps >= 3.5 ? 35.0 * wps : (wps >= 2.5 ? 50.0 * wps : 85.0 * std::max(wps, 1.0));
+    const double compute = R * row_cycles;
+    const double exchange = 480.0 + 46.0 * NW * conc;
+    const double sweep = 1.5 * (compute + exchange);
+    const double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
+    return 8800.0 + (double)rounds * (load + T * sweep);
+}
+
+bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPlan &best, double *cost_out = nullptr)
 {
     const int W = c->W, H = c->H;
     const int HX = round_up(T, 4);
@@ -213,7 +235,6 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
     bool found = false;
     for (int R = 1; R <= 8; R++) {
         if (rows && rows != R) continue;
-        const int per_simd = R <= 4 ? 4 : (R <= 5 ? 3 : 2); // wavefronts a SIMD can hold (VGPRs)
         for (int NW = 1; NW <= strip_max_waves(R); NW++) {
             if (threads && threads != NW * 64) continue;
             const int CH = NW * R - 2 * T;
@@ -222,17 +243,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
-            int wg_per_cu = std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8);
-            if (wg_per_cu < 1) continue;
-            const long long slots = (long long)kNumCU * wg_per_cu;
-            const long long rounds = (tiles + slots - 1) / slots;
-            // waves resident on the busiest SIMD while a round runs
-            const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU);
-            const int wps = (int)((conc * NW + 3) / 4);
-            // cycles: per sweep the busiest SIMD issues wps*R rows of ~115 VALU cycles plus a
-            // barrier/LDS latency; per round the tile is loaded and stored once
-            const double per_round = T * (wps * R * 115.0 + 350.0) + wps * R * 260.0 + 3000.0;
-            const double cost = (double)rounds * per_round;
+            const double cost = strip_launch_cost(T, R, NW, tiles);
             if (cost < best_cost - 1e-9) {
                 best_cost = cost;
                 found = true;
@@ -246,7 +257,26 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
             }
         }
     }
+    if (cost_out) *cost_out = best_cost;
     return found;
+}
+
+// Sweeps per launch for a budget of `iters` sweeps: minimise the modelled time of the whole solve
+// (full launches of T plus one tail launch of iters % T).
+int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p)
+{
+    double best = 1e300;
+    int bestT = 1;
+    for (int T = 1; T <= std::min(iters, 24); T++) {
+        StripPlan sp;
+        double cfull = 0, ctail = 0;
+        if (!make_strip_plan(c, T, p.strip_rows, p.threads, sp, &cfull)) continue;
+        const int rem = iters % T;
+        if (rem && !make_strip_plan(c, rem, p.strip_rows, p.threads, sp, &ctail)) continue;
+        const double total = (iters / T) * cfull + (rem ? ctail : 0.0);
+        if (total < best) { best = total; bestT = T; }
+    }
+    return bestT;
 }
 
 template <int R, int NTMAX, bool EPS>
@@ -263,7 +293,7 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
     }
     if (configure_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                       uo, vo, p.g, coeff, c->dEps);
+                       uo, vo, p.g, coeff, c->dEps, p.tiles <= 65536 ? c->dStamps : nullptr);
     return hipGetLastError();
 }
 
@@ -424,6 +454,27 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
     return HSFLOW_OK;
 }
 
+// Diagnostic only: with HSFLOW_DEBUG_STAMPS=<file> every strip launch records per-workgroup phase
+// stamps (8 x u64) and hsflow_solve appends those of the LAST launch to <file> as text.
+constexpr int kStampTiles = 65536;
+void dump_stamps(hsflow_ctx *c, int tiles)
+{
+    const char *path = getenv("HSFLOW_DEBUG_STAMPS");
+    if (!path || !c->dStamps) return;
+    tiles = std::min(tiles, kStampTiles);
+    std::vector<unsigned long long> h((size_t)tiles * 8);
+    if (hipMemcpy(h.data(), c->dStamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "# solve tiles=%d T=%d R=%d threads=%d\n", tiles, c->info.fuse_steps, c->info.groups_per_thread, c->info.threads);
+    for (int i = 0; i < tiles; i++) {
+        const unsigned long long *o = &h[(size_t)i * 8];
+        fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0],
+                o[5] - o[4], o[6], o[7]);
+    }
+    fclose(f);
+}
+
 int pick_T(int max_iter, int requested)
 {
     if (requested > 0) return std::min(requested, kMaxFuse);
@@ -463,7 +514,10 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     int T = 1;
     JPlan plan, tail;
     if (multi) {
-        T = pick_T(budget > (1 << 30) ? 8 : (int)budget, p.fuse_steps);
+        const int horizon = budget > (1 << 30) ? 64 : (int)budget; // EPS-only runs: plan for chunks
+        if (p.fuse_steps > 0) T = std::min(p.fuse_steps, kMaxFuse);
+        else if (kernel == HSFLOW_KERNEL_STRIP) T = use_eps ? std::min(8, horizon) : pick_strip_T(c, horizon, p);
+        else T = pick_T(horizon, 0);
         if (budget < T) T = (int)budget;
         if (!make_jplan(c, kernel, T, p, plan))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the requested tile/threads/rows/fuse_steps");
@@ -521,6 +575,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         if (!async) {
             HS_HIP(c, hipStreamSynchronize(c->stream));
             prof.collect();
+            if (c->dStamps && kernel == HSFLOW_KERNEL_STRIP) dump_stamps(c, plan.s.tiles);
         }
         return HSFLOW_OK;
     }
@@ -684,6 +739,7 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
         HS_TRY(hipMalloc((void **)&c->dV[i], px * sizeof(float)));
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
+    if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     HS_TRY(hipHostMalloc((void **)&c->hEps, kMaxFuse * sizeof(unsigned), hipHostMallocDefault));
     // deterministic contents for padding columns and the initial flow
     HS_TRY(hipMemsetAsync(c->dA, 0, px, c->stream));
@@ -712,6 +768,7 @@ int hsflow_destroy(hsflow_ctx *c)
     hipFree(c->dA); hipFree(c->dB); hipFree(c->dCoef);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
+    hipFree(c->dStamps);
     if (c->hEps) hipHostFree(c->hEps);
     hipFree(c->dScratch);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
