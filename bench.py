@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--pairs", type=int, default=1, help="pairs per GPU per step")
     ap.add_argument("--lam", type=float, default=1.0)
-    ap.add_argument("--kernel", choices=["auto", "simple", "fused"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "simple", "fused", "strip"], default="auto")
+    ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--fuse-steps", type=int, default=0)
     ap.add_argument("--tile-w", type=int, default=0)
     ap.add_argument("--tile-h", type=int, default=0)
@@ -73,7 +74,7 @@ def main():
     from opticalflowhs_amd import synth
 
     W, H, iters, pairs = args.width, args.height, args.iters, args.pairs
-    kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED}[args.kernel]
+    kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP}[args.kernel]
     # all work goes to one non-default stream (the legacy default stream cannot be graph-captured)
     tstream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(tstream)
@@ -90,7 +91,7 @@ def main():
 
     p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
                         fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
-                        threads=args.threads, use_graph=not args.no_graph)
+                        threads=args.threads, strip_rows=args.strip_rows, use_graph=not args.no_graph)
 
     def barrier():
         if world > 1:
@@ -119,7 +120,7 @@ def main():
     # perturb the timed region above, so they run right after it, same process, same buffers.
     pp = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
                          fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
-                         threads=args.threads, profile=True)
+                         threads=args.threads, strip_rows=args.strip_rows, profile=True)
     jac_ms = der_ms = 0.0
     launches = 0
     nprof = max(1, min(args.steps, 50))
@@ -129,6 +130,7 @@ def main():
         der_ms += pi["deriv_ms"]
         launches += pi["jacobi_launches"]
 
+    KNAME = {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused", hs.KERNEL_STRIP: "strip"}
     px = W * H * pairs
     ms_per_step = elapsed / args.steps * 1e3
     value = world * px * iters * args.steps / elapsed / 1e6
@@ -145,13 +147,13 @@ def main():
         "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, ITER termination"
                                % (W, H, pairs, args.lam, iters),
                    "width": W, "height": H, "iters": iters, "pairs_per_gpu": pairs, "lambda": args.lam,
-                   "kernel": {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused"}[info["kernel"]],
+                   "kernel": KNAME[info["kernel"]],
                    "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
-                   "threads": info["threads"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
+                   "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
                    "hipgraph": not args.no_graph, "sharding": "independent pairs per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_jacobi_fused" if info["kernel"] == hs.KERNEL_FUSED else "k_jacobi_simple",
+                     "kernel": "k_jacobi_" + KNAME[info["kernel"]],
                      "avg_launch_us": avg_launch_ms * 1e3, "sweeps_per_launch": sweeps_per_launch,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "note": "achieved = 28 B/pixel/sweep x pixels x sweeps per launch / mean launch time (HIP events); "

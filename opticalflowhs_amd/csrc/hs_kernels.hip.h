@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
                                                        float *__restrict__ u_out,
                                                        float *__restrict__ v_out, int W, int H,
                                                        int P, long long plane, float ilambda,
-                                                       unsigned *__restrict__ eps_out)
+                                                       unsigned *__restrict__ eps_out, int zero_in)
 {
+    // zero_in: the incoming flow is identically zero (first sweep of a solve): nothing is read
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const bool active = (x0 < W) && (y < H);
@@ -181,14 +182,15 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
         const long long ru = base + (long long)clampi(y - 1, 0, H - 1) * P + x0;
         const long long rd = base + (long long)clampi(y + 1, 0, H - 1) * P + x0;
         const uint4 cw = *(const uint4 *)(coef + rc);
-        const float4 uc = *(const float4 *)(u_in + rc), vc = *(const float4 *)(v_in + rc);
-        const float4 uu = *(const float4 *)(u_in + ru), vu = *(const float4 *)(v_in + ru);
-        const float4 ud = *(const float4 *)(u_in + rd), vd = *(const float4 *)(v_in + rd);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 uc = zero_in ? z4 : *(const float4 *)(u_in + rc), vc = zero_in ? z4 : *(const float4 *)(v_in + rc);
+        const float4 uu = zero_in ? z4 : *(const float4 *)(u_in + ru), vu = zero_in ? z4 : *(const float4 *)(v_in + ru);
+        const float4 ud = zero_in ? z4 : *(const float4 *)(u_in + rd), vd = zero_in ? z4 : *(const float4 *)(v_in + rd);
         // six-wide windows: [0] = pixel x0-1, [1..4] = own pixels, [5] = pixel x0+4
         float wu[6] = {uc.x, uc.x, uc.y, uc.z, uc.w, uc.w};
         float wv[6] = {vc.x, vc.x, vc.y, vc.z, vc.w, vc.w};
-        if (x0 > 0) { wu[0] = u_in[rc - 1]; wv[0] = v_in[rc - 1]; }
-        if (x0 + 4 < W) { wu[5] = u_in[rc + 4]; wv[5] = v_in[rc + 4]; }
+        if (x0 > 0 && !zero_in) { wu[0] = u_in[rc - 1]; wv[0] = v_in[rc - 1]; }
+        if (x0 + 4 < W && !zero_in) { wu[5] = u_in[rc + 4]; wv[5] = v_in[rc + 4]; }
         const float au[4] = {uu.x, uu.y, uu.z, uu.w}, av[4] = {vu.x, vu.y, vu.z, vu.w};
         const float bu[4] = {ud.x, ud.y, ud.z, ud.w}, bv[4] = {vd.x, vd.y, vd.z, vd.w};
         const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
@@ -228,6 +230,7 @@ struct FusedGeom {
     int RS;                 // LDS row stride in floats = 4*RW4 + 8 (one guard group each side)
     int G;                  // RW4 * RH
     int tiles_x, tiles_y;
+    int zero_in;            // incoming flow is identically zero: do not read u_in / v_in
 };
 
 enum : unsigned { F_ACTIVE = 1u, F_CORE = 2u, F_GU = 4u, F_GD = 8u, F_GL = 16u, F_GR = 32u };
@@ -294,7 +297,9 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
         if (valid) { // fill registers + LDS, replicate-clamped at the image border
             const int yc = clampi(y, 0, g.H - 1);
             const long long row = base + (long long)yc * g.P;
-            if (x0 >= 0 && x0 + 3 < g.W) {
+            if (g.zero_in) {
+                // cu, cv stay zero
+            } else if (x0 >= 0 && x0 + 3 < g.W) {
                 cu[k] = *(const float4 *)(u_in + row + x0);
                 cv[k] = *(const float4 *)(v_in + row + x0);
             } else {
@@ -425,6 +430,7 @@ struct StripGeom {
     int CW, CH;         // core = (256 - 2*HX) x (NW*R - 2*T)
     int NW;             // wavefronts per workgroup
     int tiles_x, tiles_y;
+    int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
 };
 
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
@@ -521,8 +527,11 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const long long off = base + (long long)mirror_index(y0 + r, g.H) * g.P + x0;
-            lu[r] = *(const float4 *)(u_in + off);
-            lv[r] = *(const float4 *)(v_in + off);
+            lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!g.zero_in) {
+                lu[r] = *(const float4 *)(u_in + off);
+                lv[r] = *(const float4 *)(v_in + off);
+            }
             lc[r] = *(const uint4 *)(coef + off);
         }
     } else {
@@ -541,8 +550,11 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
                 else { xg = 0; slow = true; }
             }
-            float4 a = *(const float4 *)(u_in + row + xg);
-            float4 b = *(const float4 *)(v_in + row + xg);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (!g.zero_in) {
+                a = *(const float4 *)(u_in + row + xg);
+                b = *(const float4 *)(v_in + row + xg);
+            }
             uint4 c = *(const uint4 *)(coef + row + xg);
             if (rev) {
                 a = make_float4(a.w, a.z, a.y, a.x);
@@ -554,8 +566,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 const volatile uint32_t *cv = coef + row;
                 const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
                           xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-                a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                if (!g.zero_in) {
+                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                }
                 c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
             }
             lu[r] = a; lv[r] = b; lc[r] = c;
@@ -688,8 +702,14 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         for (int r = 0; r < R; r++) {
             if ((rowcore >> r) & 1u) {
                 const long long off = base + (long long)(y0 + r) * g.P + x0;
+#ifdef HS_EXP_NT_STORE /* experiment: write-through stores, nothing left dirty in L2 at kernel end */
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, (v4f *)(u_out + off));
+                __builtin_nontemporal_store(v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y}, (v4f *)(v_out + off));
+#else
                 *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
                 *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
+#endif
             }
         }
     }

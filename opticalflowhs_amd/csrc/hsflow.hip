@@ -149,7 +149,7 @@ bool make_plan(const hsflow_ctx *c, int T, int tw, int th, int nt, FusedPlan &be
                     g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
                     g.CW = CW; g.CH = CH; g.T = T; g.HX = HX;
                     g.RW4 = RW4; g.RH = RH; g.RS = RS; g.G = (int)G;
-                    g.tiles_x = tx; g.tiles_y = ty;
+                    g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
                 }
             }
         }
@@ -253,7 +253,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
                 hsk::StripGeom &g = best.g;
                 g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
                 g.T = T; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
-                g.tiles_x = tx; g.tiles_y = ty;
+                g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
             }
         }
     }
@@ -323,12 +323,17 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
 }
 
 hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, bool eps, const float *ui, const float *vi,
-                    float *uo, float *vo, float coeff, bool cfg = false)
+                    float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0)
 {
-    if (pl.kind == HSFLOW_KERNEL_STRIP)
-        return eps ? launch_strip_e<true>(c, pl.s, ui, vi, uo, vo, coeff, cfg)
-                   : launch_strip_e<false>(c, pl.s, ui, vi, uo, vo, coeff, cfg);
-    return launch_fused(c, pl.f, eps, 1, ui, vi, uo, vo, coeff, cfg);
+    if (pl.kind == HSFLOW_KERNEL_STRIP) {
+        StripPlan sp = pl.s;
+        sp.g.zero_in = zero_in;
+        return eps ? launch_strip_e<true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                   : launch_strip_e<false>(c, sp, ui, vi, uo, vo, coeff, cfg);
+    }
+    FusedPlan fp = pl.f;
+    fp.g.zero_in = zero_in;
+    return launch_fused(c, fp, eps, 1, ui, vi, uo, vo, coeff, cfg);
 }
 
 void plan_to_info(hsflow_ctx *c, const JPlan &pl)
@@ -345,15 +350,15 @@ void plan_to_info(hsflow_ctx *c, const JPlan &pl)
 }
 
 hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const float *vi, float *uo,
-                         float *vo, float coeff)
+                         float *vo, float coeff, int zero_in = 0)
 {
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
     if (eps)
         hipLaunchKernelGGL(hsk::k_jacobi_simple<true>, grid, block, 0, c->stream, c->dCoef, ui, vi, uo,
-                           vo, c->W, c->H, c->P, c->plane, coeff, c->dEps);
+                           vo, c->W, c->H, c->P, c->plane, coeff, c->dEps, zero_in);
     else
         hipLaunchKernelGGL(hsk::k_jacobi_simple<false>, grid, block, 0, c->stream, c->dCoef, ui, vi,
-                           uo, vo, c->W, c->H, c->P, c->plane, coeff, c->dEps);
+                           uo, vo, c->W, c->H, c->P, c->plane, coeff, c->dEps, zero_in);
     return hipGetLastError();
 }
 
@@ -421,11 +426,10 @@ struct Profiler { // brackets kernels with events when params.profile is set
 int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters, int kernel, int T,
                   const JPlan *plan, const JPlan *tail_plan, Profiler &prof, bool do_deriv, bool zero_flow)
 {
-    if (zero_flow) {
-        c->cur = 0;
-        HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
-        HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
-    }
+    // u = v = 0 at the start (reference behaviour, use_previous = 0): instead of clearing two
+    // planes and reading them back, the first launch is told that its input is zero.
+    int zero_in = zero_flow ? 1 : 0;
+    if (zero_flow) c->cur = 0;
     if (do_deriv) {
         prof.begin(0);
         HS_HIP(c, launch_deriv(c));
@@ -436,17 +440,18 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
         const int a = c->cur, b = a ^ 1;
         if (kernel == HSFLOW_KERNEL_SIMPLE) {
             prof.begin(1);
-            HS_HIP(c, launch_simple(c, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            HS_HIP(c, launch_simple(c, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, zero_in));
             prof.end();
             left -= 1;
         } else {
             const JPlan *pl = (left >= T) ? plan : tail_plan;
             prof.begin(1);
-            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in));
             prof.end();
             left -= pl->T;
         }
         c->cur = b;
+        zero_in = 0;
         launches++;
     }
     c->info.jacobi_launches = launches;

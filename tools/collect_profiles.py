@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def find(pattern):
     r = glob.glob(pattern, recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None  # newest run wins
 
 
 def counter_per_dispatch(path, counter, kernel_substr):
