@@ -89,6 +89,8 @@ typedef struct hsflow_params {
     int32_t threads;      /* FUSED: workgroup size 256/512/1024; STRIP: 64 x wavefronts
                              per workgroup (64..1024); 0 = auto                          */
     int32_t strip_rows;   /* STRIP: rows held per lane (1..8), 0 = auto                  */
+    int32_t reuse_derivatives; /* 1: skip the derivative pass if the frames did not change since
+                             the last solve of this context (row-slab chunks, warm starts)   */
     int32_t use_graph;    /* 1: capture the launch sequence in a hipGraph and replay it  */
     int32_t profile;      /* 1: bracket every kernel with HIP events (see hsflow_info)   */
 } hsflow_params;
@@ -133,6 +135,9 @@ int hsflow_set_frames_u8_device(hsflow_ctx *ctx, int pair, const void *d_prev, s
  * the reference CPU route's pre-processing (OpticalFlowOpenCV.cpp:17,20,27-28). Synchronous. */
 int hsflow_set_frames_bgr8(hsflow_ctx *ctx, int pair, const uint8_t *prev_bgr, size_t prev_stride,
                            const uint8_t *curr_bgr, size_t curr_stride, int blur3x3);
+/* Host u8 gray frames, 3x3 box blur (cvSmooth CV_BLUR, replicate border) on the GPU. Synchronous. */
+int hsflow_set_frames_gray8_blur(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
+                                 const uint8_t *curr, size_t curr_stride);
 /* Streaming (camera loop, HSOpticalFlowOpenCL.cpp:810-834): the current frame becomes the
  * previous one on the device and only the new frame is uploaded. */
 int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t next_stride);

@@ -24,7 +24,7 @@ class HsflowParams(ctypes.Structure):
                 ("kernel", ctypes.c_int32), ("fuse_steps", ctypes.c_int32),
                 ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32),
                 ("threads", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
-                ("use_graph", ctypes.c_int32),
+                ("reuse_derivatives", ctypes.c_int32), ("use_graph", ctypes.c_int32),
                 ("profile", ctypes.c_int32)]
 
 
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "hsflow_set_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_bgr8": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i]),
+    "hsflow_set_frames_gray8_blur": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_push_frame_u8": (_i, [_vp, _i, _vp, _sz]),
     "hsflow_solve": (_i, [_vp, _pp]),
     "hsflow_solve_async": (_i, [_vp, _pp]),

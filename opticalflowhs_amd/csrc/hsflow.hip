@@ -7,6 +7,7 @@
 // :655-675), one stream, the whole launch sequence optionally captured as a hipGraph.
 #include "../../include/hsflow.h"
 #include "hs_kernels.hip.h"
+#include "hs_kernels_pre.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -542,12 +543,13 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         if (rem && !make_jplan(c, kernel, rem, p, tail))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
         const bool zero = !p.use_previous;
+        const bool do_deriv = !(p.reuse_derivatives && c->coef_valid);
         if (p.use_graph && !p.profile) {
             if (!c->stream)
                 return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
                                              "context on a non-default stream or with own_stream");
             GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
-                         c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous, coeff};
+                         c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff};
             auto it = c->graphs.find(key);
             if (it == c->graphs.end()) {
                 if (multi) { // function attributes are set outside the capture
@@ -556,7 +558,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                 }
                 HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 const int cur0 = c->cur;
-                st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, true, zero);
+                st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
                 hipGraph_t graph = nullptr;
                 hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
@@ -572,7 +574,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             c->cur = it->second.cur_after;
             c->info.jacobi_launches = it->second.launches;
         } else {
-            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, true, zero);
+            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
             if (st) return st;
         }
         c->coef_valid = true;
@@ -594,9 +596,11 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
         HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
     }
-    prof.begin(0);
-    HS_HIP(c, launch_deriv(c));
-    prof.end();
+    if (!(p.reuse_derivatives && c->coef_valid)) {
+        prof.begin(0);
+        HS_HIP(c, launch_deriv(c));
+        prof.end();
+    }
     c->coef_valid = true;
     long long done = 0;
     int launches = 0;
@@ -822,9 +826,56 @@ int hsflow_push_frame_u8(hsflow_ctx *c, int pair, const uint8_t *next, size_t ns
     return HSFLOW_OK;
 }
 
-int hsflow_set_frames_bgr8(hsflow_ctx *c, int, const uint8_t *, size_t, const uint8_t *, size_t, int)
+// Upload one host frame (colour or gray) into scratch, convert / blur on the device into dst.
+static int preprocess_frame(hsflow_ctx *c, uint8_t *dst, const uint8_t *host, size_t stride, bool colour, bool blur)
 {
-    return fail(c, HSFLOW_E_ARG, "hsflow_set_frames_bgr8: not implemented yet");
+    const size_t bgr_bytes = (size_t)c->W * 3 * c->H, gray_bytes = (size_t)c->plane;
+    const size_t need = bgr_bytes + 2 * gray_bytes;
+    if (c->scratch_bytes < need) {
+        hipFree(c->dScratch);
+        c->dScratch = nullptr; c->scratch_bytes = 0;
+        HS_HIP(c, hipMalloc(&c->dScratch, need));
+        c->scratch_bytes = need;
+    }
+    uint8_t *dBgr = (uint8_t *)c->dScratch, *dGray = dBgr + bgr_bytes;
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4), block(64, 4);
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if (colour) {
+        HS_HIP(c, hipMemcpy2D(dBgr, (size_t)c->W * 3, host, stride, (size_t)c->W * 3, c->H, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(hsk::k_bgr2gray, grid, block, 0, c->stream, dBgr, (long long)c->W * 3, blur ? dGray : dst, c->W, c->H, c->P);
+    } else {
+        HS_HIP(c, hipMemcpy2D(blur ? dGray : dst, c->P, host, stride, c->W, c->H, hipMemcpyHostToDevice));
+    }
+    if (blur) hipLaunchKernelGGL(hsk::k_box_blur3, grid, block, 0, c->stream, dGray, dst, c->W, c->H, c->P);
+    HS_HIP(c, hipGetLastError());
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_bgr8(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs, int blur3x3)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W * 3 || cs < (size_t)c->W * 3) return fail(c, HSFLOW_E_SIZE, "colour frame stride smaller than 3*width");
+    if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, true, blur3x3 != 0))) return st;
+    if ((st = preprocess_frame(c, c->dB + pair * c->plane, curr, cs, true, blur3x3 != 0))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_gray8_blur(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, false, true))) return st;
+    if ((st = preprocess_frame(c, c->dB + pair * c->plane, curr, cs, false, true))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
 }
 
 int hsflow_solve(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, false); }

@@ -1,0 +1,159 @@
+"""Row-slab decomposition of ONE large frame over several GPUs (BASELINE config C5).
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  Rank r owns the contiguous rows [lo_r, hi_r) of the frame and holds them plus
+`halo` extra rows above and below in its own solver context.  The Jacobi update at row y needs
+u, v at rows y-1 and y+1 only, so after k sweeps the rows closer than k to a slab's artificial edge
+are stale; the driver therefore runs the sweeps in chunks of at most `halo`, and after every chunk
+neighbouring ranks swap `halo` rows of u and v (send/recv point to point, no collective).  The
+derivative pass needs frame rows y-1..y+1, which the overlapping upload already provides.  The
+result is bit-identical to solving the whole frame on one GPU.
+
+The module contains no arithmetic: the per-slab solver is any object with the small interface of
+`HSFlowSlabBackend` below (the product one wraps the HIP context; the CPU tests inject one that
+wraps the oracle, which is test infrastructure and never imported from here).
+"""
+import numpy as np
+
+
+def slab_rows(height, world, rank):
+    """Rows [lo, hi) owned by `rank`: contiguous, sizes differ by at most one."""
+    base, extra = divmod(height, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def slab_extent(height, world, rank, halo):
+    """(lo, hi, top, bot): owned rows and the halo depths actually available above / below."""
+    lo, hi = slab_rows(height, world, rank)
+    top = min(halo, lo)
+    bot = min(halo, height - hi)
+    return lo, hi, top, bot
+
+
+def chunks(total, size):
+    """Sweep counts of the successive chunks: as many `size` as fit, then the remainder."""
+    out = [size] * (total // size)
+    if total % size:
+        out.append(total % size)
+    return out
+
+
+class HSFlowSlabBackend(object):
+    """Per-rank solver over the local rows (product implementation: the HIP context)."""
+
+    def __init__(self, hs, width, local_height, device, stream=None):
+        import torch
+        self.torch = torch
+        self.hs = hs
+        self.ctx = hs.HSFlow(width, local_height, 1, device=device, stream=stream, own_stream=stream is None)
+        self.width, self.height, self.device = width, local_height, device
+
+    def set_frames(self, prev, curr):
+        self.ctx.set_frames(prev, curr)
+
+    def sweep(self, n, lam, first):
+        # derivatives are computed by the first chunk only; later chunks continue from the flow
+        self.ctx.solve(lam=lam, max_iter=n, term_type=self.hs.TERM_ITER, use_previous=not first,
+                       reuse_derivatives=not first)
+
+    def new_rows(self, nrows):
+        t = self.torch
+        dev = "cuda:%d" % self.device
+        return (t.empty((nrows, self.width), dtype=t.float32, device=dev),
+                t.empty((nrows, self.width), dtype=t.float32, device=dev))
+
+    def get_rows(self, row0, u, v):
+        self.ctx.flow_rows_to(u, v, row0, u.shape[0])
+        self.ctx.synchronize()
+
+    def put_rows(self, row0, u, v):
+        self.torch.cuda.synchronize(self.device)  # the received rows were written on torch's stream
+        self.ctx.set_flow_rows_from(u, v, row0, u.shape[0])
+        self.ctx.synchronize()
+
+    def flow(self):
+        return self.ctx.flow()
+
+    def close(self):
+        self.ctx.close()
+
+
+class SlabSolver(object):
+    """Drives one rank's slab: chunked sweeps + halo exchange with the ranks above and below."""
+
+    def __init__(self, dist, rank, world, width, height, halo, make_backend):
+        if halo < 1:
+            raise ValueError("halo must be >= 1")
+        if world > 1 and height // world < halo:
+            raise ValueError("slabs of %d rows are thinner than the halo (%d)" % (height // world, halo))
+        self.dist, self.rank, self.world = dist, rank, world
+        self.width, self.height, self.halo = width, height, halo
+        self.lo, self.hi, self.top, self.bot = slab_extent(height, world, rank, halo)
+        self.row0 = self.lo - self.top                    # first frame row held locally
+        self.local_height = (self.hi + self.bot) - self.row0
+        self.backend = make_backend(width, self.local_height)
+        self._bufs = None
+
+    def local_frame_rows(self):
+        """Frame rows [row0, row1) this rank must upload (owned rows + halos)."""
+        return self.row0, self.row0 + self.local_height
+
+    def set_frames(self, prev_local, curr_local):
+        if prev_local.shape != (self.local_height, self.width):
+            raise ValueError("local frames must have shape (%d, %d)" % (self.local_height, self.width))
+        self.backend.set_frames(prev_local, curr_local)
+
+    def _exchange(self):
+        """Swap `halo` rows of u, v with the neighbouring ranks (2 sends + 2 recvs per neighbour)."""
+        d, b, h = self.dist, self.backend, self.halo
+        if self._bufs is None:
+            self._bufs = {k: b.new_rows(h) for k in ("send_up", "recv_up", "send_dn", "recv_dn")}
+        ops = []
+        up, dn = self.rank - 1, self.rank + 1
+        if up >= 0:      # my first owned rows become the bottom halo of the rank above
+            su, sv = self._bufs["send_up"]
+            b.get_rows(self.top, su, sv)
+            ru, rv = self._bufs["recv_up"]
+            ops += [d.P2POp(d.isend, su, up), d.P2POp(d.isend, sv, up),
+                    d.P2POp(d.irecv, ru, up), d.P2POp(d.irecv, rv, up)]
+        if dn < self.world:  # my last owned rows become the top halo of the rank below
+            su, sv = self._bufs["send_dn"]
+            b.get_rows(self.top + (self.hi - self.lo) - h, su, sv)
+            ru, rv = self._bufs["recv_dn"]
+            ops += [d.P2POp(d.isend, su, dn), d.P2POp(d.isend, sv, dn),
+                    d.P2POp(d.irecv, ru, dn), d.P2POp(d.irecv, rv, dn)]
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        if up >= 0:
+            ru, rv = self._bufs["recv_up"]
+            b.put_rows(0, ru, rv)                                   # rows [lo-halo, lo)
+        if dn < self.world:
+            ru, rv = self._bufs["recv_dn"]
+            b.put_rows(self.top + (self.hi - self.lo), ru, rv)      # rows [hi, hi+halo)
+
+    def solve(self, lam, iters):
+        """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchanges."""
+        n_ex = 0
+        plan = chunks(iters, self.halo) if self.world > 1 else [iters]
+        for i, n in enumerate(plan):
+            self.backend.sweep(n, lam, first=(i == 0))
+            if self.world > 1 and i + 1 < len(plan):
+                self._exchange()
+                n_ex += 1
+        return n_ex
+
+    def owned_flow(self):
+        """(u, v) of the rows this rank owns, as host arrays of shape (hi - lo, width)."""
+        u, v = self.backend.flow()
+        u, v = np.asarray(u), np.asarray(v)
+        return u[self.top:self.top + (self.hi - self.lo)], v[self.top:self.top + (self.hi - self.lo)]
+
+    def close(self):
+        self.backend.close()
+
+
+def shard_pairs(n_pairs, world, rank):
+    """Independent pairs (BASELINE config C4): pair i runs on rank i mod world; no collective."""
+    return list(range(rank, n_pairs, world))

@@ -107,6 +107,15 @@ class HSFlow(object):
         self._check(self._lib.hsflow_set_frames_bgr8(self._h, pair, _ptr(prev_bgr), prev_bgr.strides[0],
                                                      _ptr(curr_bgr), curr_bgr.strides[0], 1 if blur else 0))
 
+    def set_frames_gray_blur(self, prev, curr, pair=0):
+        """u8 gray frames, 3x3 box blur on the GPU first (the reference CPU route's cvSmooth)."""
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        curr = np.ascontiguousarray(curr, dtype=np.uint8)
+        if prev.shape != (self.height, self.width) or curr.shape != prev.shape:
+            raise ValueError("frame shape must be (height, width)")
+        self._check(self._lib.hsflow_set_frames_gray8_blur(self._h, pair, _ptr(prev), prev.strides[0],
+                                                           _ptr(curr), curr.strides[0]))
+
     def push_frame(self, nxt, pair=0):
         nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
         if nxt.shape != (self.height, self.width):
@@ -116,7 +125,8 @@ class HSFlow(object):
     # -- solve ---------------------------------------------------------------------------
     def make_params(self, lam=1.0, max_iter=100, epsilon=1e-6, term_type=TERM_ITER | TERM_EPS,
                     use_previous=False, mode=MODE_CV, alpha=1.0, kernel=KERNEL_AUTO, fuse_steps=0,
-                    tile_w=0, tile_h=0, threads=0, strip_rows=0, use_graph=False, profile=False):
+                    tile_w=0, tile_h=0, threads=0, strip_rows=0, reuse_derivatives=False, use_graph=False,
+                    profile=False):
         p = HsflowParams()
         self._lib.hsflow_default_params(ctypes.byref(p))
         p.mode = mode
@@ -132,6 +142,7 @@ class HSFlow(object):
         p.tile_h = tile_h
         p.threads = threads
         p.strip_rows = strip_rows
+        p.reuse_derivatives = 1 if reuse_derivatives else 0
         p.use_graph = 1 if use_graph else 0
         p.profile = 1 if profile else 0
         return p

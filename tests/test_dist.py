@@ -1,0 +1,57 @@
+"""Multi-process tests of the N > 1 paths on CPU (gloo, world_size 2 and 3).
+
+Independent pairs shard with no collective (only the index arithmetic is testable without a GPU);
+the row-slab mode has a real exchange step, checked here end to end against the single-domain
+oracle result, bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from opticalflowhs_amd import slab, synth
+
+
+def test_slab_partition_arithmetic():
+    for H in (7, 64, 1080, 16384):
+        for world in (1, 2, 3, 8):
+            rows = [slab.slab_rows(H, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == H
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
+    lo, hi, top, bot = slab.slab_extent(100, 4, 0, 8)
+    assert (lo, hi, top, bot) == (0, 25, 0, 8)
+    lo, hi, top, bot = slab.slab_extent(100, 4, 3, 8)
+    assert (lo, hi, top, bot) == (75, 100, 8, 0)
+    assert slab.chunks(100, 16) == [16] * 6 + [4] and slab.chunks(8, 8) == [8] and slab.chunks(5, 8) == [5]
+    # independent pairs: every pair exactly once, round robin
+    got = sorted(i for r in range(8) for i in slab.shard_pairs(512, 8, r))
+    assert got == list(range(512)) and len(slab.shard_pairs(512, 8, 3)) == 64
+    with pytest.raises(ValueError):
+        slab.SlabSolver(None, 0, 4, 32, 20, 8, lambda w, h: None)  # 5-row slabs, halo 8
+
+
+@pytest.mark.parametrize("world,halo,iters", [(2, 4, 10), (2, 8, 8), (3, 5, 23)])
+def test_slab_exchange_matches_single_domain(tmp_path, oracle, world, halo, iters):
+    W, H = 96, 61
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world * 10 + halo),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(W), str(H), str(halo), str(iters), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    A, B = synth.translating_pair(W, H, seed=3)
+    uo, vo = oracle.calc_optical_flow_hs(A, B, 0.7, iters, term_type=1)
+    u = np.zeros_like(uo)
+    v = np.zeros_like(vo)
+    pairs = []
+    for rank in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        u[int(d["lo"]):int(d["hi"])] = d["u"]
+        v[int(d["lo"]):int(d["hi"])] = d["v"]
+        assert int(d["n_ex"]) == len(slab.chunks(iters, halo)) - 1
+        pairs += list(d["pairs"])
+    assert np.array_equal(u, uo) and np.array_equal(v, vo)
+    assert sorted(pairs) == list(range(11))

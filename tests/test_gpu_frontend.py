@@ -1,0 +1,130 @@
+"""GPU tests of the rows either side of the hot path: the pre-processing kernels
+(BGR->gray, 3x3 box blur), streaming frames, and the C++ drop-in (class + CLI) built by `make host`."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from opticalflowhs_amd import synth
+
+pytestmark = pytest.mark.gpu
+ITER, EPS = 1, 2
+
+
+def rms(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def write_pnm(path, img):
+    with open(path, "wb") as f:
+        if img.ndim == 2:
+            f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        else:
+            f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
+
+
+def read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = (int(x) for x in f.readline().split())
+        assert f.readline().strip() == b"255"
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("shape", [(9, 13), (48, 64), (61, 203), (1, 5), (5, 1), (240, 424)])
+def test_preprocessing_bit_exact(hs, oracle, gpu_ok, shape):
+    H, W = shape
+    rng = np.random.default_rng(H * 7 + W)
+    a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames_bgr(a, b, blur=False)
+        ga, gb = ctx.frames()
+        assert np.array_equal(ga, oracle.bgr2gray(a)) and np.array_equal(gb, oracle.bgr2gray(b))
+        ctx.set_frames_bgr(a, b, blur=True)
+        fa, fb = ctx.frames()
+        assert np.array_equal(fa, oracle.box_blur3(oracle.bgr2gray(a)))
+        assert np.array_equal(fb, oracle.box_blur3(oracle.bgr2gray(b)))
+        ctx.set_frames_gray_blur(ga, gb)
+        fa2, fb2 = ctx.frames()
+        assert np.array_equal(fa2, fa) and np.array_equal(fb2, fb)
+
+
+def test_bunny_end_to_end_from_gray(hs, gpu_ok):
+    """BASELINE config C1 as the reference's CPU route runs it: blur inside, lambda 1, 50 iterations,
+    ITER|EPS with eps 1e-6 (OpticalFlowOpenCV.cpp:26-30), here entirely on the GPU."""
+    from PIL import Image  # PGM decoding only
+    g = [np.asarray(Image.open(os.path.join(GOLDEN, "bunny_%d_gray.pgm" % i))) for i in (1, 2)]
+    d = np.load(os.path.join(GOLDEN, "bunny_flow_l1_i50.npz"))
+    with hs.HSFlow(424, 240, 1, own_stream=True) as ctx:
+        ctx.set_frames_gray_blur(g[0], g[1])
+        info = ctx.solve(lam=1.0, max_iter=50, epsilon=float(np.float32(1e-6)), term_type=ITER | EPS)
+        u, v = ctx.flow()
+    assert info["iterations_done"] == 50
+    assert rms(u, d["u"]) <= 1e-4 and rms(v, d["v"]) <= 1e-4
+
+
+def test_streaming_push_frame(hs, oracle, gpu_ok):
+    W, H = 160, 96
+    frames = [synth.translating_pair(W, H, seed=5, dx=0.5 * k, dy=0.25 * k)[1] for k in range(4)]
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(frames[0], frames[1])
+        for k in range(1, 4):
+            if k > 1:
+                ctx.push_frame(frames[k])          # frame k-1 stays on the device as "previous"
+            ctx.solve(lam=1.0, max_iter=25, term_type=ITER)
+            u, v = ctx.flow()
+            uo, vo = oracle.calc_optical_flow_hs(frames[k - 1], frames[k], 1.0, 25, term_type=ITER)
+            assert rms(u, uo) <= 1e-4 and rms(v, vo) <= 1e-4
+            a, b = ctx.frames()
+            assert np.array_equal(a, frames[k - 1]) and np.array_equal(b, frames[k])
+
+
+def test_reuse_derivatives_flag(hs, gpu_ok):
+    A, B = synth.random_pair(90, 50, seed=3)
+    with hs.HSFlow(90, 50, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        ctx.solve(lam=0.4, max_iter=12, term_type=ITER)
+        u12, v12 = ctx.flow()
+        ctx.solve(lam=0.4, max_iter=5, term_type=ITER)
+        ctx.solve(lam=0.4, max_iter=7, term_type=ITER, use_previous=True, reuse_derivatives=True)
+        u, v = ctx.flow()
+        assert np.array_equal(u, u12) and np.array_equal(v, v12)
+
+
+def test_cpp_dropin_cli(hs, oracle, gpu_ok, tmp_path):
+    """The reference's positional command line, served by the C++ class over the C ABI."""
+    cli = os.path.join(ROOT, "opticalflowhs_amd", "hsflow_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "opticalflowhs_amd", "csrc"), "-s", "host"])
+    W, H = 200, 120
+    A, B = synth.translating_pair(W, H, seed=9, dx=2.5, dy=-1.5)
+    p1, p2 = str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm")
+    write_pnm(p1, A)
+    write_pnm(p2, B)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "opticalflowhs_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    # -cv route: blur + HS(lambda) + arrows for |flow| > 1
+    out_cv = str(tmp_path / "cv.ppm")
+    r = subprocess.run([cli, "-cv", "-hd", p1, p2, out_cv, "0.1", "60"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Avg time" in r.stdout, r.stdout + r.stderr
+    img = read_ppm(out_cv)
+    fa, fb = oracle.box_blur3(A), oracle.box_blur3(B)
+    uo, vo = oracle.calc_optical_flow_hs(fa, fb, 0.1, 60, float(np.float32(1e-6)), ITER | EPS)
+    want_dots = sum(1 for y in range(0, H, 4) for x in range(0, W, 4) if abs(uo[y, x]) > 1 or abs(vo[y, x]) > 1)
+    dots = sum(1 for y in range(0, H, 4) for x in range(0, W, 4) if tuple(img[y, x]) == (0, 0, 255))
+    assert want_dots > 20 and abs(dots - want_dots) <= max(2, want_dots // 50)
+    # -cl route: alpha, fixed iteration count, GPU
+    out_cl = str(tmp_path / "cl.ppm")
+    r = subprocess.run([cli, "-cl", "-hd", p1, p2, out_cl, "3", "40", "1", "GPU"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and os.path.getsize(out_cl) == W * H * 3 + len(b"P6\n%d %d\n255\n" % (W, H))
+    # refused / malformed invocations keep the reference's behaviour
+    r = subprocess.run([cli, "-cl", "-hd", p1, p2, out_cl, "3", "40", "1", "CPU"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "CPU" in r.stdout
+    r = subprocess.run([cli, "-cv", "-hd", p1, p2], env=env, capture_output=True, text=True, timeout=60)
+    assert "Wrong argument list" in r.stdout
+    r = subprocess.run([cli, "-cv", "-hd", str(tmp_path / "missing.pgm"), p2, out_cv, "0.1", "5"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and "Input image error" in r.stdout
