@@ -115,7 +115,7 @@ def test_cpp_dropin_cli(hs, oracle, gpu_ok, tmp_path):
     fa, fb = oracle.box_blur3(A), oracle.box_blur3(B)
     uo, vo = oracle.calc_optical_flow_hs(fa, fb, 0.1, 60, float(np.float32(1e-6)), ITER | EPS)
     want_dots = sum(1 for y in range(0, H, 4) for x in range(0, W, 4) if abs(uo[y, x]) > 1 or abs(vo[y, x]) > 1)
-    dots = sum(1 for y in range(0, H, 4) for x in range(0, W, 4) if tuple(img[y, x]) == (0, 0, 255))
+    dots = sum(1 for y in range(0, H, 4) for x in range(0, W, 4) if img[y, x].any())  # dot centre, possibly under the line
     assert want_dots > 20 and abs(dots - want_dots) <= max(2, want_dots // 50)
     # -cl route: alpha, fixed iteration count, GPU
     out_cl = str(tmp_path / "cl.ppm")
