@@ -65,10 +65,21 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py needs a GPU (the product path has no CPU fallback)\n")
         sys.exit(2)
+    # one rank per GPU; HSFLOW_BENCH_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 code path
+    # (ranks then share the card, so that run says nothing about scaling)
+    backend = os.environ.get("HSFLOW_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        sys.stderr.write("bench.py: %d ranks but %d GPUs\n" % (world, ndev))
+        sys.exit(2)
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import opticalflowhs_amd as hs
     from opticalflowhs_amd import synth
@@ -110,7 +121,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = ctx.info()
