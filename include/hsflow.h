@@ -68,6 +68,8 @@ extern "C" {
 #define HSFLOW_KERNEL_STRIP 3  /* `fuse_steps` iterations per launch on register-resident strips:
                                   a wavefront holds 256 columns x strip_rows rows in VGPRs, DPP
                                   for left/right, LDS only for strip-edge rows (AUTO picks this) */
+#define HSFLOW_KERNEL_FOLD 4   /* as STRIP, two 128-column strips per wavefront (half the LDS
+                                  exchange; inner boundary swapped in registers)              */
 
 typedef struct hsflow_ctx hsflow_ctx;
 
@@ -88,7 +90,7 @@ typedef struct hsflow_params {
     int32_t tile_h;       /* FUSED: core tile height, 0 = auto                           */
     int32_t threads;      /* FUSED: workgroup size 256/512/1024; STRIP: 64 x wavefronts
                              per workgroup (64..1024); 0 = auto                          */
-    int32_t strip_rows;   /* STRIP: rows held per lane (1..8), 0 = auto                  */
+    int32_t strip_rows;   /* STRIP / FOLD: rows held per lane (1..8), 0 = auto           */
     int32_t reuse_derivatives; /* 1: skip the derivative pass if the frames did not change since
                              the last solve of this context (row-slab chunks, warm starts)   */
     int32_t use_graph;    /* 1: capture the launch sequence in a hipGraph and replay it  */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("HSFLOW_LIB_PATH") or os.path.join(HERE, "libhsflow.so
 OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
 TERM_ITER, TERM_EPS = 1, 2
 MODE_CV, MODE_CLASSIC = 0, 1
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP, KERNEL_FOLD = 0, 1, 2, 3, 4
 
 
 class HsflowParams(ctypes.Structure):

@@ -10,8 +10,8 @@
 //   * no per-iteration host<->device copies;
 //   * image files are binary PGM/PPM (no OpenCV highgui on this platform);
 //   * dType "CPU" is refused: this build has no CPU path.
-// The "-cl" route keeps its parameter alpha; the solver runs the OpenCV discretisation (the
-// graded semantics) with lambda = 1 / alpha^2, which is the same regulariser.
+// The "-cl" route runs the reference kernels' own discretisation (HSFLOW_MODE_CLASSIC, alpha);
+// the "-cv" route (class OpticalFlowOpenCV below) runs the OpenCV one (graded semantics).
 #pragma once
 #include <string>
 #include <vector>

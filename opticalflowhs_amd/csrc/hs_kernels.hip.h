@@ -162,16 +162,16 @@ __global__ __launch_bounds__(256) void k_unpack_deriv(const uint32_t *__restrict
 //     One lane = 4 consecutive pixels; block = 64 lanes x 4 rows.  Up/down rows and the two
 //     side pixels come from L1/L2.  20 B/pixel of compulsory traffic (4 coef + 8 read + 8 write).
 // ------------------------------------------------------------------------------------------
-template <bool EPS>
+template <bool EPS, bool ZERO>
 __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restrict__ coef,
                                                        const float *__restrict__ u_in,
                                                        const float *__restrict__ v_in,
                                                        float *__restrict__ u_out,
                                                        float *__restrict__ v_out, int W, int H,
                                                        int P, long long plane, float ilambda,
-                                                       unsigned *__restrict__ eps_out, int zero_in)
+                                                       unsigned *__restrict__ eps_out)
 {
-    // zero_in: the incoming flow is identically zero (first sweep of a solve): nothing is read
+    // ZERO: the incoming flow is identically zero (first sweep of a solve): nothing is read
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const bool active = (x0 < W) && (y < H);
@@ -182,15 +182,17 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
         const long long ru = base + (long long)clampi(y - 1, 0, H - 1) * P + x0;
         const long long rd = base + (long long)clampi(y + 1, 0, H - 1) * P + x0;
         const uint4 cw = *(const uint4 *)(coef + rc);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 uc = zero_in ? z4 : *(const float4 *)(u_in + rc), vc = zero_in ? z4 : *(const float4 *)(v_in + rc);
-        const float4 uu = zero_in ? z4 : *(const float4 *)(u_in + ru), vu = zero_in ? z4 : *(const float4 *)(v_in + ru);
-        const float4 ud = zero_in ? z4 : *(const float4 *)(u_in + rd), vd = zero_in ? z4 : *(const float4 *)(v_in + rd);
+        float4 uc = make_float4(0.f, 0.f, 0.f, 0.f), vc = uc, uu = uc, vu = uc, ud = uc, vd = uc;
+        if (!ZERO) {
+            uc = *(const float4 *)(u_in + rc); vc = *(const float4 *)(v_in + rc);
+            uu = *(const float4 *)(u_in + ru); vu = *(const float4 *)(v_in + ru);
+            ud = *(const float4 *)(u_in + rd); vd = *(const float4 *)(v_in + rd);
+        }
         // six-wide windows: [0] = pixel x0-1, [1..4] = own pixels, [5] = pixel x0+4
         float wu[6] = {uc.x, uc.x, uc.y, uc.z, uc.w, uc.w};
         float wv[6] = {vc.x, vc.x, vc.y, vc.z, vc.w, vc.w};
-        if (x0 > 0 && !zero_in) { wu[0] = u_in[rc - 1]; wv[0] = v_in[rc - 1]; }
-        if (x0 + 4 < W && !zero_in) { wu[5] = u_in[rc + 4]; wv[5] = v_in[rc + 4]; }
+        if (!ZERO && x0 > 0) { wu[0] = u_in[rc - 1]; wv[0] = v_in[rc - 1]; }
+        if (!ZERO && x0 + 4 < W) { wu[5] = u_in[rc + 4]; wv[5] = v_in[rc + 4]; }
         const float au[4] = {uu.x, uu.y, uu.z, uu.w}, av[4] = {vu.x, vu.y, vu.z, vu.w};
         const float bu[4] = {ud.x, ud.y, ud.z, ud.w}, bv[4] = {vd.x, vd.y, vd.z, vd.w};
         const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         __builtin_amdgcn_sched_barrier(0); /* one row at a time keeps the VGPR pressure down */    \
     } while (0)
 #endif
-#ifdef HS_DIAG_NO_EXCHANGE /* diagnostic build only: wrong results, times the VALU part alone */
+#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS) /* diagnostic builds only: wrong results */
 #define HS_PUBLISH(buf) do { } while (0)
 #else
 #define HS_PUBLISH(buf)                                                                            \
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
 #pragma unroll 1
     for (int s = 0; s < g.T; s++) {
-#ifdef HS_DIAG_NO_EXCHANGE
+#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
 #else
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
             e = wave_max(e);
             if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
         }
-#ifndef HS_DIAG_NO_EXCHANGE
+#if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (s + 1 < g.T) __syncthreads();
 #endif
     }
@@ -719,6 +721,223 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
         o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); // XCC_ID
+        o[7] = (unsigned long long)tile;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2, form 4: "folded" strips.  Same register-resident scheme as k_jacobi_strip, but one wavefront
+// holds TWO vertically adjacent strips of 128 columns: lanes 0-31 the upper one (rows top->bottom
+// in registers 0..R-1), lanes 32-63 the lower one in MIRRORED order (register r = block row
+// 2R-1-r).  Both halves then have their wave-internal boundary at register row R-1 and their
+// outer edge at register row 0, so
+//   * the inner boundary is exchanged inside the wavefront (v_permlane32_swap, no LDS),
+//   * each wavefront publishes ONE row per half through LDS (2 ds_write_b128 + 2 ds_read_b128 per
+//     sweep instead of 4 + 4) -- the LDS edge-row exchange is what bounds the strip kernel,
+//   * no per-half selects are needed: the update is symmetric in up/down, so the lower half simply
+//     walks its rows in the opposite direction.
+// The DPP wave shifts cross the lane 31/32 seam, which is harmless: lanes 31 and 32 sit on the
+// region's right / left edge (junk the validity argument tolerates).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_xor32(float x, bool lower)
+{
+    // value of the same register in lane (l ^ 32)
+    const unsigned b = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false); // r[0] = {lo, lo}, r[1] = {hi, hi}
+    return __uint_as_float(lower ? r[0] : r[1]);
+}
+
+template <int R, int NTMAX, bool EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
+                                                       const float *__restrict__ u_in,
+                                                       const float *__restrict__ v_in,
+                                                       float *__restrict__ u_out,
+                                                       float *__restrict__ v_out, const StripGeom g,
+                                                       const float ilambda,
+                                                       unsigned *__restrict__ eps_out,
+                                                       unsigned long long *__restrict__ stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32]
+    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
+    if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool lower = lane >= 32;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NW = g.NW;
+    const int tpp = g.tiles_x * g.tiles_y;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int pair = tile / tpp;
+    const int t2 = tile - pair * tpp;
+    const int by = t2 / g.tiles_x, bx = t2 - by * g.tiles_x;
+    const int rx0 = bx * g.CW - g.HX;
+    const int x0 = rx0 + 4 * hl;
+    const int yb = by * g.CH - g.T + w * 2 * R; // first block row of this wavefront
+    const long long base = (long long)pair * g.plane;
+    const bool xin = (x0 >= 0) && (x0 + 3 < g.W);
+
+    f2 uP[R], uQ[R], vP[R], vQ[R];
+    RowCoef cf[R];
+    float4 lu[R], lv[R];
+    uint4 lc[R];
+    const bool side = !(rx0 >= 0 && rx0 + 128 <= g.W); // workgroup-uniform
+    int xg = x0;
+    bool rev = false, slow = false;
+    if (side && !xin) { // see k_jacobi_strip: mirrored aligned group, or the general scalar path
+        if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; rev = true; }
+        else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
+        else { xg = 0; slow = true; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int y = yb + (lower ? 2 * R - 1 - r : r);
+        const long long row = base + (long long)mirror_index(y, g.H) * g.P;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (!g.zero_in) {
+            a = *(const float4 *)(u_in + row + xg);
+            b = *(const float4 *)(v_in + row + xg);
+        }
+        uint4 c = *(const uint4 *)(coef + row + xg);
+        if (side) {
+            if (rev) {
+                a = make_float4(a.w, a.z, a.y, a.x);
+                b = make_float4(b.w, b.z, b.y, b.x);
+                c = make_uint4(c.w, c.z, c.y, c.x);
+            }
+            if (slow) { // volatile keeps this a separate, rarely taken path
+                const volatile float *uv = u_in + row, *vv = v_in + row;
+                const volatile uint32_t *cv = coef + row;
+                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
+                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
+                if (!g.zero_in) {
+                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                }
+                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+            }
+        }
+        lu[r] = a; lv[r] = b; lc[r] = c;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uP[r] = f2{lu[r].x, lu[r].y}; uQ[r] = f2{lu[r].z, lu[r].w};
+        vP[r] = f2{lv[r].x, lv[r].y}; vQ[r] = f2{lv[r].z, lv[r].w};
+        float Ix[4], Iy[4], It[4], a[4];
+        const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            unpack_deriv(cc[p], Ix[p], Iy[p], It[p]);
+            a[p] = alpha_of(Ix[p], Iy[p], ilambda);
+        }
+        cf[r].IxP = f2{Ix[0], Ix[1]}; cf[r].IxQ = f2{Ix[2], Ix[3]};
+        cf[r].IyP = f2{Iy[0], Iy[1]}; cf[r].IyQ = f2{Iy[2], Iy[3]};
+        cf[r].ItP = f2{It[0], It[1]}; cf[r].ItQ = f2{It[2], It[3]};
+        cf[r].aP = f2{a[0], a[1]};    cf[r].aQ = f2{a[2], a[3]};
+    }
+    // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
+    unsigned rowcore = 0;
+    int rdist[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int jl = w * 2 * R + (lower ? 2 * R - 1 - r : r), y = yb + (lower ? 2 * R - 1 - r : r);
+        if (jl >= g.T && jl < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
+        const int ju = w * 2 * R + r, jd = w * 2 * R + 2 * R - 1 - r;
+        const int du = ju < g.T ? g.T - ju : (ju >= g.T + g.CH ? ju - (g.T + g.CH - 1) : 0);
+        const int dd = jd < g.T ? g.T - jd : (jd >= g.T + g.CH ? jd - (g.T + g.CH - 1) : 0);
+        rdist[r] = du < dd ? du : dd; // the row is computed while either half still needs it
+    }
+    const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * hl >= g.HX) && (4 * hl < g.HX + g.CW);
+    const int pr = g.W - 1 - x0;
+
+#define HF_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
+    do {                                                                                           \
+        if (rdist[r] <= g.T - 1 - s) {                                                             \
+            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
+            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
+            if (EPS) {                                                                             \
+                if (((rowcore >> r) & 1u) && lanecore) {                                           \
+                    e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
+                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
+                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ouQ.x - uQ[r].x), fabsf(ovQ.x - vQ[r].x))); \
+                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ouQ.y - uQ[r].y), fabsf(ovQ.y - vQ[r].y))); \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+    // slot of (buffer, wavefront, half): two planes of 32 float4
+#define HF_SLOT(buf, ww, hh) (ex + ((size_t)(((buf) * NW + (ww)) * 2 + (hh)) * 2) * 32)
+#define HF_PUBLISH(buf)                                                                            \
+    do {                                                                                           \
+        float4 *exw = HF_SLOT(buf, w, lower ? 1 : 0) + hl;                                         \
+        exw[0] = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y);                                  \
+        exw[32] = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);                                 \
+    } while (0)
+
+    HF_PUBLISH(0);
+    __syncthreads();
+    if (stamps) st1 = __builtin_amdgcn_s_memtime();
+    // outer neighbour: upper half <- bottom row of the wavefront above (its half 1),
+    //                  lower half <- top row of the wavefront below (its half 0);
+    // at the region edge the wavefront's own slot stands in (junk the validity argument tolerates)
+    const int wo = lower ? (w < NW - 1 ? w + 1 : w) : (w > 0 ? w - 1 : w);
+    const int ho = lower ? (w < NW - 1 ? 0 : 1) : (w > 0 ? 1 : 0);
+#pragma unroll 1
+    for (int s = 0; s < g.T; s++) {
+        const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
+        const float4 h4u = eo[0], h4v = eo[32];
+        const f2 ouP_ = f2{h4u.x, h4u.y}, ouQ_ = f2{h4u.z, h4u.w}, ovP_ = f2{h4v.x, h4v.y}, ovQ_ = f2{h4v.z, h4v.w};
+        // inner neighbour: the other half's register row R-1 (old values), in-register exchange
+        const f2 iuP = f2{lane_xor32(uP[R - 1].x, lower), lane_xor32(uP[R - 1].y, lower)};
+        const f2 iuQ = f2{lane_xor32(uQ[R - 1].x, lower), lane_xor32(uQ[R - 1].y, lower)};
+        const f2 ivP = f2{lane_xor32(vP[R - 1].x, lower), lane_xor32(vP[R - 1].y, lower)};
+        const f2 ivQ = f2{lane_xor32(vQ[R - 1].x, lower), lane_xor32(vQ[R - 1].y, lower)};
+        float e = 0.f;
+        // register row 0 (the published outer edge) first, so that its LDS write drains under the
+        // other rows; then rows 1..R-1 walking towards the inner boundary, keeping one old row
+        f2 puP = uP[0], puQ = uQ[0], pvP = vP[0], pvQ = vQ[0];
+        if (R == 1) {
+            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, iuP, iuQ, ivP, ivQ);
+        } else {
+            constexpr int R1 = R > 1 ? 1 : 0;
+            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
+        }
+        if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+            const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
+            const int rn = r + 1 < R ? r + 1 : r;
+            if (r == R - 1) HF_ROW(r, puP, puQ, pvP, pvQ, iuP, iuQ, ivP, ivQ);
+            else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
+            puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
+        }
+        if (EPS) {
+            e = wave_max(e);
+            if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
+        }
+        if (s + 1 < g.T) __syncthreads();
+    }
+#undef HF_ROW
+#undef HF_PUBLISH
+#undef HF_SLOT
+    if (stamps) st2 = __builtin_amdgcn_s_memtime();
+
+    if (lanecore) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((rowcore >> r) & 1u) {
+                const int y = yb + (lower ? 2 * R - 1 - r : r);
+                const long long off = base + (long long)y * g.P + x0;
+                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
+            }
+        }
+    }
+    if (stamps && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
         o[7] = (unsigned long long)tile;
     }
 }

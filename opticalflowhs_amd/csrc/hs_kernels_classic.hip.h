@@ -1,0 +1,99 @@
+// hs_kernels_classic.hip.h -- the reference's own OpenCL discretisation ("-cl" route), re-written
+// for gfx950 with the v update restored:
+//   ComputeDerivativesKernel   OpticalFlowHS/Kernels.cl:13-39   2x2x2 cube differences over both frames
+//   u_v_avgKernel              OpticalFlowHS/Kernels.cl:43-68   1/6 (W,E,N,S) + 1/12 (corners)
+//   u_v_updateKernel           OpticalFlowHS/Kernels.cl:71-90   alpha^2 regulariser; writes u AND v here
+// The two per-iteration kernels of the reference are fused into one pass (u_avg / v_avg never touch
+// memory) and the planes are planar fp32 instead of float4.  Evaluation order = source order of
+// Kernels.cl without contraction, i.e. exactly oracle/hs_classic_oracle.c (bit-exact parity).
+// One sweep per launch, 9-point stencil straight from L1/L2: this secondary mode is HBM-bound at
+// 12 (Ex,Ey,Et) + 8 + 8 bytes per pixel per sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hsk {
+
+__global__ __launch_bounds__(256) void k_deriv_classic(const uint8_t *__restrict__ A, const uint8_t *__restrict__ B,
+                                                       float *__restrict__ Ex, float *__restrict__ Ey,
+                                                       float *__restrict__ Et, int W, int H, int P, long long plane)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const long long base = (long long)blockIdx.z * plane;
+    const int y1 = y < H - 1 ? y + 1 : H - 1; // Tex2D clamp (Kernels.cl:2-9)
+    const uint8_t *a0 = A + base + (long long)y * P, *a1 = A + base + (long long)y1 * P;
+    const uint8_t *b0 = B + base + (long long)y * P, *b1 = B + base + (long long)y1 * P;
+    float ra0[5], ra1[5], rb0[5], rb1[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int xc = x0 + k < W - 1 ? x0 + k : W - 1;
+        ra0[k] = (float)a0[xc]; ra1[k] = (float)a1[xc];
+        rb0[k] = (float)b0[xc]; rb1[k] = (float)b1[xc];
+    }
+    float ex[4], ey[4], et[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float a00 = ra0[k], a10 = ra0[k + 1], a01 = ra1[k], a11 = ra1[k + 1];
+        const float b00 = rb0[k], b10 = rb0[k + 1], b01 = rb1[k], b11 = rb1[k + 1];
+        ex[k] = 0.25f * (a10 - a00 + a11 - a01 + b10 - b00 + b11 - b01);
+        ey[k] = 0.25f * (a01 - a00 + a11 - a10 + b01 - b00 + b11 - b10);
+        et[k] = 0.25f * (b00 - a00 + b10 - a10 + b01 - a01 + b11 - a11);
+    }
+    const long long o = base + (long long)y * P + x0;
+    *(float4 *)(Ex + o) = make_float4(ex[0], ex[1], ex[2], ex[3]);
+    *(float4 *)(Ey + o) = make_float4(ey[0], ey[1], ey[2], ey[3]);
+    *(float4 *)(Et + o) = make_float4(et[0], et[1], et[2], et[3]);
+}
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void k_jacobi_classic(const float *__restrict__ Ex, const float *__restrict__ Ey,
+                                                        const float *__restrict__ Et, const float *__restrict__ u_in,
+                                                        const float *__restrict__ v_in, float *__restrict__ u_out,
+                                                        float *__restrict__ v_out, int W, int H, int P,
+                                                        long long plane, float alpha2)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const long long base = (long long)blockIdx.z * plane;
+    const long long rows[3] = {base + (long long)(y > 0 ? y - 1 : 0) * P, base + (long long)y * P,
+                               base + (long long)(y < H - 1 ? y + 1 : H - 1) * P};
+    float wu[3][6], wv[3][6]; // columns x0-1 .. x0+4 (clamped) of rows y-1, y, y+1
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float4 cu = make_float4(0.f, 0.f, 0.f, 0.f), cv = cu;
+        float lu = 0.f, lv = 0.f, ru = 0.f, rv = 0.f;
+        if (!ZERO) {
+            cu = *(const float4 *)(u_in + rows[j] + x0);
+            cv = *(const float4 *)(v_in + rows[j] + x0);
+            lu = x0 > 0 ? u_in[rows[j] + x0 - 1] : cu.x;
+            lv = x0 > 0 ? v_in[rows[j] + x0 - 1] : cv.x;
+            ru = x0 + 4 < W ? u_in[rows[j] + x0 + 4] : 0.f;
+            rv = x0 + 4 < W ? v_in[rows[j] + x0 + 4] : 0.f;
+        }
+        wu[j][0] = lu; wu[j][1] = cu.x; wu[j][2] = cu.y; wu[j][3] = cu.z; wu[j][4] = cu.w; wu[j][5] = ru;
+        wv[j][0] = lv; wv[j][1] = cv.x; wv[j][2] = cv.y; wv[j][3] = cv.z; wv[j][4] = cv.w; wv[j][5] = rv;
+    }
+    const long long o = base + (long long)y * P + x0;
+    const float4 e4x = *(const float4 *)(Ex + o), e4y = *(const float4 *)(Ey + o), e4t = *(const float4 *)(Et + o);
+    const float ex[4] = {e4x.x, e4x.y, e4x.z, e4x.w}, ey[4] = {e4y.x, e4y.y, e4y.z, e4y.w}, et[4] = {e4t.x, e4t.y, e4t.z, e4t.w};
+    const float c6 = (float)(1.0 / 6), c12 = (float)(1.0 / 12); // Kernels.cl:55,57 (double literals, converted)
+    float nu[4], nv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // clamp to edge in x: the last image column is its own right neighbour
+        const int r = (x0 + k >= W - 1) ? k + 1 : k + 2, c = k + 1, l = k;
+        const float ua = c6 * (wu[1][l] + wu[1][r] + wu[0][c] + wu[2][c]) + c12 * (wu[0][l] + wu[0][r] + wu[2][l] + wu[2][r]);
+        const float va = c6 * (wv[1][l] + wv[1][r] + wv[0][c] + wv[2][c]) + c12 * (wv[0][l] + wv[0][r] + wv[2][l] + wv[2][r]);
+        float t = ex[k] * ua + ey[k] * va + et[k];
+        t /= alpha2 + ex[k] * ex[k] + ey[k] * ey[k];
+        nu[k] = ua - ex[k] * t;
+        nv[k] = va - ey[k] * t; // restored: the reference kernel forgot this line (Kernels.cl:84-86)
+    }
+    *(float4 *)(u_out + o) = make_float4(nu[0], nu[1], nu[2], nu[3]);
+    *(float4 *)(v_out + o) = make_float4(nv[0], nv[1], nv[2], nv[3]);
+}
+
+} // namespace hsk

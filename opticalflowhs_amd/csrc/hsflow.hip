@@ -8,6 +8,7 @@
 #include "../../include/hsflow.h"
 #include "hs_kernels.hip.h"
 #include "hs_kernels_pre.hip.h"
+#include "hs_kernels_classic.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -35,11 +36,12 @@ struct FusedPlan {
 struct StripPlan {
     hsk::StripGeom g;
     int R, lds_bytes, tiles;
+    int fold; // 0: k_jacobi_strip (256 columns, one strip per wavefront); 1: k_jacobi_fold (128 columns, two)
 };
 
 // A launch plan for T sweeps with either multi-sweep kernel.
 struct JPlan {
-    int kind = 0; // HSFLOW_KERNEL_FUSED or HSFLOW_KERNEL_STRIP
+    int kind = 0; // HSFLOW_KERNEL_FUSED, HSFLOW_KERNEL_STRIP or HSFLOW_KERNEL_FOLD
     int T = 0;
     FusedPlan f{};
     StripPlan s{};
@@ -71,6 +73,8 @@ struct hsflow_ctx {
     bool own_stream = false;
     uint8_t *dA = nullptr, *dB = nullptr;
     uint32_t *dCoef = nullptr;
+    float *dE[3] = {nullptr, nullptr, nullptr}; // CLASSIC mode: Ex, Ey, Et planes (allocated on first use)
+    int coef_mode = -1;          // discretisation the current derivatives belong to
     float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
     unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
     unsigned *dEps = nullptr;   // kMaxFuse words
@@ -208,10 +212,10 @@ int strip_max_waves(int R) { return R <= 4 ? 16 : (R <= 5 ? 12 : 8); }
 // Cost model (shader cycles at ~2.2 GHz), fitted to in-kernel phase stamps on MI355X at 1080p
 // (tools/stamps.py; profiles/): one launch = fixed launch/drain gap + per round [tile load +
 // T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
-double strip_launch_cost(int T, int R, int NW, long long tiles, int *wg_per_cu_out = nullptr)
+double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, int *wg_per_cu_out = nullptr)
 {
     const int per_simd = R <= 4 ? 4 : (R <= 5 ? 3 : 2);
-    const int lds = NW * 8192;
+    const int lds = NW * (fold ? 4096 : 8192);
     const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
     if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
     const long long slots = (long long)kNumCU * wg_per_cu;
@@ -220,17 +224,17 @@ double strip_launch_cost(int T, int R, int NW, long long tiles, int *wg_per_cu_o
     const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
     const double row_cycles = wps >= 3.5 ? 35.0 * wps : (wps >= 2.5 ? 50.0 * wps : 85.0 * std::max(wps, 1.0));
     const double compute = R * row_cycles;
-    const double exchange = 480.0 + 46.0 * NW * conc;
+    const double exchange = 480.0 + (fold ? 30.0 : 46.0) * NW * conc + (fold ? 120.0 : 0.0);
     const double sweep = 1.5 * (compute + exchange);
     const double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
     return 8800.0 + (double)rounds * (load + T * sweep);
 }
 
-bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPlan &best, double *cost_out = nullptr)
+bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold, StripPlan &best, double *cost_out = nullptr)
 {
     const int W = c->W, H = c->H;
     const int HX = round_up(T, 4);
-    const int CW = 256 - 2 * HX;
+    const int CW = (fold ? 128 : 256) - 2 * HX;
     if (CW < 4) return false;
     double best_cost = 1e300;
     bool found = false;
@@ -238,17 +242,18 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
         if (rows && rows != R) continue;
         for (int NW = 1; NW <= strip_max_waves(R); NW++) {
             if (threads && threads != NW * 64) continue;
-            const int CH = NW * R - 2 * T;
+            const int CH = NW * R * (fold ? 2 : 1) - 2 * T;
             if (CH < 1) continue;
-            const int lds = NW * 8192;
+            const int lds = NW * (fold ? 4096 : 8192);
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
-            const double cost = strip_launch_cost(T, R, NW, tiles);
+            const double cost = strip_launch_cost(T, R, NW, tiles, fold);
             if (cost < best_cost - 1e-9) {
                 best_cost = cost;
                 found = true;
                 best.R = R;
+                best.fold = fold;
                 best.lds_bytes = lds;
                 best.tiles = (int)tiles;
                 hsk::StripGeom &g = best.g;
@@ -264,27 +269,27 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, StripPla
 
 // Sweeps per launch for a budget of `iters` sweeps: minimise the modelled time of the whole solve
 // (full launches of T plus one tail launch of iters % T).
-int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p)
+int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fold)
 {
     double best = 1e300;
     int bestT = 1;
     for (int T = 1; T <= std::min(iters, 24); T++) {
         StripPlan sp;
         double cfull = 0, ctail = 0;
-        if (!make_strip_plan(c, T, p.strip_rows, p.threads, sp, &cfull)) continue;
+        if (!make_strip_plan(c, T, p.strip_rows, p.threads, fold, sp, &cfull)) continue;
         const int rem = iters % T;
-        if (rem && !make_strip_plan(c, rem, p.strip_rows, p.threads, sp, &ctail)) continue;
+        if (rem && !make_strip_plan(c, rem, p.strip_rows, p.threads, fold, sp, &ctail)) continue;
         const double total = (iters / T) * cfull + (rem ? ctail : 0.0);
         if (total < best) { best = total; bestT = T; }
     }
     return bestT;
 }
 
-template <int R, int NTMAX, bool EPS>
+template <int R, int NTMAX, bool EPS, bool FOLD>
 hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                           float *uo, float *vo, float coeff, bool configure_only)
 {
-    auto kern = hsk::k_jacobi_strip<R, NTMAX, EPS>;
+    auto kern = FOLD ? hsk::k_jacobi_fold<R, NTMAX, EPS> : hsk::k_jacobi_strip<R, NTMAX, EPS>;
     static bool configured[64] = {};
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -298,19 +303,19 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
     return hipGetLastError();
 }
 
-template <bool EPS>
+template <bool EPS, bool FOLD>
 hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                           float *uo, float *vo, float coeff, bool cfg)
 {
     switch (p.R) {
-    case 1: return launch_strip_t<1, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 2: return launch_strip_t<2, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 3: return launch_strip_t<3, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 4: return launch_strip_t<4, 1024, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 5: return launch_strip_t<5, 768, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 6: return launch_strip_t<6, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 7: return launch_strip_t<7, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 8: return launch_strip_t<8, 512, EPS>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 1: return launch_strip_t<1, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 2: return launch_strip_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 3: return launch_strip_t<3, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 4: return launch_strip_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5: return launch_strip_t<5, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 6: return launch_strip_t<6, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 7: return launch_strip_t<7, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 8: return launch_strip_t<8, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     }
     return hipErrorInvalidConfiguration;
 }
@@ -319,18 +324,21 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
 {
     out.kind = kind;
     out.T = T;
-    if (kind == HSFLOW_KERNEL_STRIP) return make_strip_plan(c, T, p.strip_rows, p.threads, out.s);
+    if (kind == HSFLOW_KERNEL_STRIP) return make_strip_plan(c, T, p.strip_rows, p.threads, 0, out.s);
+    if (kind == HSFLOW_KERNEL_FOLD) return make_strip_plan(c, T, p.strip_rows, p.threads, 1, out.s);
     return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
 }
 
 hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, bool eps, const float *ui, const float *vi,
                     float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0)
 {
-    if (pl.kind == HSFLOW_KERNEL_STRIP) {
+    if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         StripPlan sp = pl.s;
         sp.g.zero_in = zero_in;
-        return eps ? launch_strip_e<true>(c, sp, ui, vi, uo, vo, coeff, cfg)
-                   : launch_strip_e<false>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        if (sp.fold) return eps ? launch_strip_e<true, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                : launch_strip_e<false, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        return eps ? launch_strip_e<true, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                   : launch_strip_e<false, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
     }
     FusedPlan fp = pl.f;
     fp.g.zero_in = zero_in;
@@ -341,7 +349,7 @@ void plan_to_info(hsflow_ctx *c, const JPlan &pl)
 {
     hsflow_info &i = c->info;
     i.fuse_steps = pl.T;
-    if (pl.kind == HSFLOW_KERNEL_STRIP) {
+    if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         i.tile_w = pl.s.g.CW; i.tile_h = pl.s.g.CH; i.threads = pl.s.g.NW * 64;
         i.groups_per_thread = pl.s.R; i.tiles = pl.s.tiles; i.lds_bytes = pl.s.lds_bytes;
     } else {
@@ -354,12 +362,12 @@ hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const f
                          float *vo, float coeff, int zero_in = 0)
 {
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
-    if (eps)
-        hipLaunchKernelGGL(hsk::k_jacobi_simple<true>, grid, block, 0, c->stream, c->dCoef, ui, vi, uo,
-                           vo, c->W, c->H, c->P, c->plane, coeff, c->dEps, zero_in);
-    else
-        hipLaunchKernelGGL(hsk::k_jacobi_simple<false>, grid, block, 0, c->stream, c->dCoef, ui, vi,
-                           uo, vo, c->W, c->H, c->P, c->plane, coeff, c->dEps, zero_in);
+#define HS_SIMPLE(E, Z)                                                                            \
+    hipLaunchKernelGGL((hsk::k_jacobi_simple<E, Z>), grid, block, 0, c->stream, c->dCoef, ui, vi, uo, vo, \
+                       c->W, c->H, c->P, c->plane, coeff, c->dEps)
+    if (eps) { if (zero_in) HS_SIMPLE(true, true); else HS_SIMPLE(true, false); }
+    else { if (zero_in) HS_SIMPLE(false, true); else HS_SIMPLE(false, false); }
+#undef HS_SIMPLE
     return hipGetLastError();
 }
 
@@ -491,6 +499,57 @@ int pick_T(int max_iter, int requested)
     return std::min(8, std::max(1, max_iter));
 }
 
+// CLASSIC mode (Kernels.cl semantics, v restored): derivatives once, then max_iter fused
+// average+update sweeps, one launch each.  The reference loop has no other stop rule
+// (HSOpticalFlowOpenCL.cpp:750-751), so only ITER termination is accepted.
+int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
+{
+    if (p.term_type != HSFLOW_TERM_ITER) return fail(c, HSFLOW_E_ARG, "CLASSIC mode supports ITER termination only");
+    if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+    if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
+    if (p.use_graph || (async && p.profile)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: use_graph / async profiling not supported");
+    const size_t px = (size_t)c->plane * c->N;
+    for (int i = 0; i < 3; i++)
+        if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
+    Profiler prof{c, p.profile != 0};
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC)) {
+        prof.begin(0);
+        hipLaunchKernelGGL(hsk::k_deriv_classic, grid, block, 0, c->stream, c->dA, c->dB, c->dE[0], c->dE[1], c->dE[2],
+                           c->W, c->H, c->P, c->plane);
+        HS_HIP(c, hipGetLastError());
+        prof.end();
+    }
+    c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CLASSIC;
+    const float a2 = p.alpha * p.alpha; // Kernels.cl:85
+    int zero = p.use_previous ? 0 : 1;
+    if (zero) c->cur = 0;
+    for (int it = 0; it < p.max_iter; it++) {
+        const int a = c->cur, b = a ^ 1;
+        prof.begin(1);
+        if (zero)
+            hipLaunchKernelGGL(hsk::k_jacobi_classic<true>, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2],
+                               c->dU[a], c->dV[a], c->dU[b], c->dV[b], c->W, c->H, c->P, c->plane, a2);
+        else
+            hipLaunchKernelGGL(hsk::k_jacobi_classic<false>, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2],
+                               c->dU[a], c->dV[a], c->dU[b], c->dV[b], c->W, c->H, c->P, c->plane, a2);
+        HS_HIP(c, hipGetLastError());
+        prof.end();
+        c->cur = b;
+        zero = 0;
+    }
+    hsflow_info &i = c->info;
+    i.kernel = HSFLOW_KERNEL_SIMPLE; i.fuse_steps = 1; i.tile_w = i.tile_h = 0; i.threads = 256;
+    i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0; i.jacobi_launches = p.max_iter;
+    i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
+    if (!async) {
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        prof.collect();
+    }
+    return HSFLOW_OK;
+}
+
 int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
 {
     int st = check_ctx(c, 0);
@@ -499,7 +558,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
     const hsflow_params &p = *pp;
     if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
-    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "mode not implemented");
+    if (p.mode == HSFLOW_MODE_CLASSIC) return solve_classic(c, p, async);
+    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
     const bool use_iter = (p.term_type & HSFLOW_TERM_ITER) != 0, use_eps = (p.term_type & HSFLOW_TERM_EPS) != 0;
     if (!use_iter && !use_eps) return fail(c, HSFLOW_E_ARG, "term_type must include ITER and/or EPS");
     if (use_iter && p.max_iter <= 0 && !use_eps)
@@ -510,7 +570,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
 
     const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
     const int kernel = p.kernel == HSFLOW_KERNEL_AUTO ? HSFLOW_KERNEL_STRIP : p.kernel;
-    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP)
+    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP &&
+        kernel != HSFLOW_KERNEL_FOLD)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
     const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
     // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
@@ -522,7 +583,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     if (multi) {
         const int horizon = budget > (1 << 30) ? 64 : (int)budget; // EPS-only runs: plan for chunks
         if (p.fuse_steps > 0) T = std::min(p.fuse_steps, kMaxFuse);
-        else if (kernel == HSFLOW_KERNEL_STRIP) T = use_eps ? std::min(8, horizon) : pick_strip_T(c, horizon, p);
+        else if (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)
+            T = use_eps ? std::min(8, horizon) : pick_strip_T(c, horizon, p, kernel == HSFLOW_KERNEL_FOLD);
         else T = pick_T(horizon, 0);
         if (budget < T) T = (int)budget;
         if (!make_jplan(c, kernel, T, p, plan))
@@ -543,7 +605,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         if (rem && !make_jplan(c, kernel, rem, p, tail))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
         const bool zero = !p.use_previous;
-        const bool do_deriv = !(p.reuse_derivatives && c->coef_valid);
+        const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
         if (p.use_graph && !p.profile) {
             if (!c->stream)
                 return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
@@ -578,11 +640,12 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             if (st) return st;
         }
         c->coef_valid = true;
+        c->coef_mode = HSFLOW_MODE_CV;
         c->info.iterations_done = iters;
         if (!async) {
             HS_HIP(c, hipStreamSynchronize(c->stream));
             prof.collect();
-            if (c->dStamps && kernel == HSFLOW_KERNEL_STRIP) dump_stamps(c, plan.s.tiles);
+            if (c->dStamps && (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)) dump_stamps(c, plan.s.tiles);
         }
         return HSFLOW_OK;
     }
@@ -596,12 +659,13 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
         HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
     }
-    if (!(p.reuse_derivatives && c->coef_valid)) {
+    if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
         prof.begin(0);
         HS_HIP(c, launch_deriv(c));
         prof.end();
     }
     c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CV;
     long long done = 0;
     int launches = 0;
     float last = 0.f;
@@ -775,6 +839,7 @@ int hsflow_destroy(hsflow_ctx *c)
     }
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     hipFree(c->dA); hipFree(c->dB); hipFree(c->dCoef);
+    for (int i = 0; i < 3; i++) hipFree(c->dE[i]);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
     hipFree(c->dStamps);
@@ -949,6 +1014,13 @@ int hsflow_get_derivatives(hsflow_ctx *c, int pair, float *dx, float *dy, float 
         c->dScratch = nullptr; c->scratch_bytes = 0;
         HS_HIP(c, hipMalloc(&c->dScratch, need));
         c->scratch_bytes = need;
+    }
+    if (c->coef_mode == HSFLOW_MODE_CLASSIC) { // planar fp32 already: strided copies
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        float *dst[3] = {dx, dy, dt};
+        for (int i = 0; i < 3; i++)
+            HS_HIP(c, hipMemcpy2D(dst[i], stride, c->dE[i] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
+        return HSFLOW_OK;
     }
     float *sx = (float *)c->dScratch, *sy = sx + (size_t)c->W * c->H, *stt = sy + (size_t)c->W * c->H;
     hipLaunchKernelGGL(hsk::k_unpack_deriv, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,

@@ -96,6 +96,36 @@ def test_reuse_derivatives_flag(hs, gpu_ok):
         assert np.array_equal(u, u12) and np.array_equal(v, v12)
 
 
+@pytest.mark.parametrize("shape", [(18, 24), (61, 203), (1, 7), (7, 1), (2, 2), (240, 424)])
+def test_classic_mode_bit_exact(hs, oracle, gpu_ok, shape):
+    """Kernels.cl semantics with the v update restored, against its oracle."""
+    H, W = shape
+    A, B = synth.smooth_random_pair(W, H, seed=H + W, shift=(1, 0)) if min(H, W) > 2 else synth.random_pair(W, H, seed=3)
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        for alpha, it in ((15.0, 1), (15.0, 20), (1.0, 7)):
+            info = ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER)
+            assert info["iterations_done"] == it
+            u, v = ctx.flow()
+            uo, vo = oracle.classic_flow(A, B, alpha, it)
+            assert np.array_equal(u, uo) and np.array_equal(v, vo), (alpha, it)
+        ex, ey, et = ctx.derivatives()
+        Ex, Ey, Et = oracle.classic_derivatives(A, B)
+        assert np.array_equal(ex, Ex) and np.array_equal(ey, Ey) and np.array_equal(et, Et)
+        # continuing from the current flow, and switching back to the CV discretisation
+        ctx.solve(mode=hs.MODE_CLASSIC, alpha=3.0, max_iter=4, term_type=ITER)
+        ctx.solve(mode=hs.MODE_CLASSIC, alpha=3.0, max_iter=5, term_type=ITER, use_previous=True, reuse_derivatives=True)
+        u, v = ctx.flow()
+        uo, vo = oracle.classic_flow(A, B, 3.0, 9)
+        assert np.array_equal(u, uo) and np.array_equal(v, vo)
+        ctx.solve(lam=0.5, max_iter=6, term_type=ITER)
+        u, v = ctx.flow()
+        uo, vo = oracle.calc_optical_flow_hs(A, B, 0.5, 6, term_type=ITER)
+        assert rms(u, uo) <= 1e-4 and rms(v, vo) <= 1e-4
+        with pytest.raises(hs.HsflowError):
+            ctx.solve(mode=hs.MODE_CLASSIC, alpha=1.0, max_iter=5, term_type=ITER | EPS)
+
+
 def test_cpp_dropin_cli(hs, oracle, gpu_ok, tmp_path):
     """The reference's positional command line, served by the C++ class over the C ABI."""
     cli = os.path.join(ROOT, "opticalflowhs_amd", "hsflow_cli")

@@ -77,11 +77,11 @@ def test_derivatives_bit_exact(hs, oracle, gpu_ok, shape):
 
 
 @pytest.mark.parametrize("shape", [(29, 37), (48, 64), (1, 9), (9, 1), (2, 2), (3, 3), (1, 1), (7, 130), (131, 6)])
-@pytest.mark.parametrize("kernel", ["simple", "fused", "strip"])
+@pytest.mark.parametrize("kernel", ["simple", "fused", "strip", "fold"])
 def test_small_random_pairs(hs, oracle, gpu_ok, shape, kernel):
     H, W = shape
     A, B = synth.random_pair(W, H, seed=H * 131 + W)
-    k = {"simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP}[kernel]
+    k = {"simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP, "fold": hs.KERNEL_FOLD}[kernel]
     for lam in (0.01, 1.0, 10.0):
         for it in (1, 2, 10, 100):
             uo, vo = oracle.calc_optical_flow_hs(A, B, lam, it, term_type=ITER)
@@ -128,6 +128,10 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
     for T, R, nt in ((1, 1, 256), (2, 2, 192), (3, 3, 1024), (4, 4, 1024), (5, 5, 768), (7, 6, 512), (9, 7, 512),
                      (12, 8, 512), (8, 3, 640), (30, 8, 512), (6, 1, 1024)):
         variants.append(dict(kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=nt))
+    variants += [dict(kernel=hs.KERNEL_FOLD), dict(kernel=hs.KERNEL_FOLD, use_graph=True)]
+    for T, R, nt in ((1, 1, 128), (2, 2, 128), (3, 3, 1024), (4, 4, 1024), (5, 5, 768), (7, 6, 512), (9, 7, 512),
+                     (12, 8, 512), (8, 3, 320), (30, 8, 512), (6, 1, 1024), (11, 4, 448)):
+        variants.append(dict(kernel=hs.KERNEL_FOLD, fuse_steps=T, strip_rows=R, threads=nt))
     variants += [
                  dict(kernel=hs.KERNEL_SIMPLE, use_graph=True)]
     for kw in variants:
@@ -142,7 +146,8 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
 def test_eps_termination_matches_oracle(hs, gpu_ok):
     d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
     for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5),
-               dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, fuse_steps=7, strip_rows=2)):
+               dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, fuse_steps=7, strip_rows=2),
+               dict(kernel=hs.KERNEL_FOLD), dict(kernel=hs.KERNEL_FOLD, fuse_steps=5, strip_rows=3)):
         u, v, info = gpu_solve(hs, d["A"], d["B"], 0.002, 500, eps=1e-3, tt=ITER | EPS, **kw)
         assert abs(info["iterations_done"] - int(d["iters"])) <= 1, info
         assert info["last_eps"] < 1e-3
@@ -261,10 +266,11 @@ def test_1080p_full_frame_parity(hs, oracle, gpu_ok):
     A, B = synth.translating_pair(1920, 1080, seed=1)
     uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 100, term_type=ITER, threads=0)
     u, v, info = gpu_solve(hs, A, B, 1.0, 100)
-    assert info["kernel"] == hs.KERNEL_STRIP
-    check("c2_1080p_strip", (u, v), (uo, vo))
-    uf, vf, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=hs.KERNEL_FUSED)
-    assert np.array_equal(u, uf) and np.array_equal(v, vf)
+    assert info["kernel"] in (hs.KERNEL_STRIP, hs.KERNEL_FOLD)
+    check("c2_1080p_auto", (u, v), (uo, vo))
+    for k in (hs.KERNEL_FUSED, hs.KERNEL_FOLD, hs.KERNEL_STRIP):
+        uf, vf, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=k)
+        assert np.array_equal(u, uf) and np.array_equal(v, vf), k
     us, vs, _ = gpu_solve(hs, A, B, 1.0, 100, kernel=hs.KERNEL_SIMPLE)
     assert np.array_equal(u, us) and np.array_equal(v, vs)
     ug, vg, _ = gpu_solve(hs, A, B, 1.0, 100, use_graph=True)
@@ -276,7 +282,9 @@ def test_4k_full_frame_parity(hs, oracle, gpu_ok):
     A, B = synth.translating_pair(3840, 2160, seed=2)
     uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, 200, term_type=ITER, threads=0)
     u, v, _ = gpu_solve(hs, A, B, 1.0, 200)
-    check("c3_4k_strip", (u, v), (uo, vo))
+    check("c3_4k_auto", (u, v), (uo, vo))
+    uf, vf, _ = gpu_solve(hs, A, B, 1.0, 200, kernel=hs.KERNEL_FOLD)
+    assert np.array_equal(u, uf) and np.array_equal(v, vf)
     us, vs, _ = gpu_solve(hs, A, B, 1.0, 200, kernel=hs.KERNEL_SIMPLE)
     assert np.array_equal(u, us) and np.array_equal(v, vs)
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pairs", type=int, default=1)
+    ap.add_argument("--kernel", default="strip", choices=["strip", "fold"])
     ap.add_argument("--configs", default="10:4:1024;10:5:768;12:4:1024;5:4:1024;8:8:512", help="T:R:threads;...")
     args = ap.parse_args()
     path = tempfile.mktemp(prefix="hs_stamps_")
@@ -28,13 +29,14 @@ def main():
     for i in range(args.pairs):
         A, B = synth.translating_pair(args.width, args.height, seed=1 + i)
         ctx.set_frames(A, B, pair=i)
+    KERN = hs.KERNEL_FOLD if args.kernel == "fold" else hs.KERNEL_STRIP
     for cfg in args.configs.split(";"):
         T, R, nt = [int(x) for x in cfg.split(":")]
         for _ in range(3):  # warm
-            ctx.solve(lam=1.0, max_iter=4 * T, term_type=hs.TERM_ITER, kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=nt)
+            ctx.solve(lam=1.0, max_iter=4 * T, term_type=hs.TERM_ITER, kernel=KERN, fuse_steps=T, strip_rows=R, threads=nt)
         if os.path.exists(path):
             os.remove(path)
-        info = ctx.solve(lam=1.0, max_iter=4 * T, term_type=hs.TERM_ITER, kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=nt)
+        info = ctx.solve(lam=1.0, max_iter=4 * T, term_type=hs.TERM_ITER, kernel=KERN, fuse_steps=T, strip_rows=R, threads=nt)
         rows = np.array([[int(x) for x in l.split()] for l in open(path) if not l.startswith("#")], dtype=np.float64)
         load, sweeps, store, total, rt, xcc = rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 4], rows[:, 5], rows[:, 6]
         ghz = total.sum() / (rt.sum() * 10.0)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--strip", default="", help="strip-kernel sweep: comma list of rows per lane, e.g. 1,2,3,4,5,6,7,8")
     ap.add_argument("--waves", default="4,6,8,10,12,14,16", help="strip-kernel sweep: wavefronts per workgroup")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--fold", default="", help="fold-kernel sweep: comma list of rows per lane")
     args = ap.parse_args()
 
     import torch
@@ -46,7 +47,8 @@ def main():
         A, B = synth.translating_pair(W, H, seed=1 if args.pairs == 1 else 1000 + i)
         ctx.set_frames(A, B, pair=i)
 
-    variants = [("auto", dict()), ("simple", dict(kernel=hs.KERNEL_SIMPLE)), ("fused_auto", dict(kernel=hs.KERNEL_FUSED))]
+    variants = [("auto", dict()), ("simple", dict(kernel=hs.KERNEL_SIMPLE)), ("fused_auto", dict(kernel=hs.KERNEL_FUSED)),
+                ("strip_auto", dict(kernel=hs.KERNEL_STRIP)), ("fold_auto", dict(kernel=hs.KERNEL_FOLD))]
     for T in [int(x) for x in args.fuse.split(",") if x]:
         for R in [int(x) for x in args.strip.split(",") if x]:
             for NW in [int(x) for x in args.waves.split(",") if x]:
@@ -54,6 +56,13 @@ def main():
                     continue
                 variants.append(("S_T%d_R%d_NW%d" % (T, R, NW),
                                  dict(kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=NW * 64)))
+    for T in [int(x) for x in args.fuse.split(",") if x]:
+        for R in [int(x) for x in args.fold.split(",") if x]:
+            for NW in [int(x) for x in args.waves.split(",") if x]:
+                if NW * R * 2 - 2 * T < 1 or NW > (16 if R <= 4 else 12 if R == 5 else 8):
+                    continue
+                variants.append(("F_T%d_R%d_NW%d" % (T, R, NW),
+                                 dict(kernel=hs.KERNEL_FOLD, fuse_steps=T, strip_rows=R, threads=NW * 64)))
     for T in [int(x) for x in args.fuse.split(",") if x]:
         if iters % T or args.no_fused:
             continue
@@ -117,7 +126,7 @@ def main():
     for med, name, mn, rate, tiles, lds, k, nt, tw, th, T in rows[:15]:
         print("%-28s med %.4f ms  min %.4f ms  %9.0f Mpix*it/s  tiles %4d lds %6d" % (name, med, mn, rate, tiles, lds))
     for med, name, mn, rate, tiles, lds, k, nt, tw, th, T in rows:
-        if name in ("auto", "simple", "fused_auto"):
+        if name in ("auto", "simple", "fused_auto", "strip_auto", "fold_auto"):
             print("%-28s med %.4f ms  min %.4f ms  %9.0f Mpix*it/s  tiles %4d (T %d tile %dx%d nt %d)" % (name, med, mn, rate, tiles, T, tw, th, nt))
     ctx.close()
 
