@@ -82,7 +82,9 @@ class HSFlowSlabBackend(object):
 class SlabSolver(object):
     """Drives one rank's slab: chunked sweeps + halo exchange with the ranks above and below."""
 
-    def __init__(self, dist, rank, world, width, height, halo, make_backend):
+    def __init__(self, dist, rank, world, width, height, halo, make_backend, stage_on_host=False):
+        # stage_on_host: exchange through host copies of the halo rows (gloo rehearsals of the GPU
+        # path on a box whose ranks share one card; RCCL sends device buffers directly)
         if halo < 1:
             raise ValueError("halo must be >= 1")
         if world > 1 and height // world < halo:
@@ -93,6 +95,7 @@ class SlabSolver(object):
         self.row0 = self.lo - self.top                    # first frame row held locally
         self.local_height = (self.hi + self.bot) - self.row0
         self.backend = make_backend(width, self.local_height)
+        self.stage_on_host = stage_on_host
         self._bufs = None
 
     def local_frame_rows(self):
@@ -111,27 +114,43 @@ class SlabSolver(object):
             self._bufs = {k: b.new_rows(h) for k in ("send_up", "recv_up", "send_dn", "recv_dn")}
         ops = []
         up, dn = self.rank - 1, self.rank + 1
+        host = self.stage_on_host
+        wire = {}
+
+        def out(name):  # tensor that goes on the wire for send buffer `name`
+            t = self._bufs[name]
+            wire[name] = (t[0].cpu(), t[1].cpu()) if host else t
+            return wire[name]
+
+        def inn(name):  # tensor the wire writes into for recv buffer `name`
+            t = self._bufs[name]
+            wire[name] = (t[0].cpu(), t[1].cpu()) if host else t
+            return wire[name]
+
         if up >= 0:      # my first owned rows become the bottom halo of the rank above
-            su, sv = self._bufs["send_up"]
-            b.get_rows(self.top, su, sv)
-            ru, rv = self._bufs["recv_up"]
+            b.get_rows(self.top, *self._bufs["send_up"])
+            su, sv = out("send_up")
+            ru, rv = inn("recv_up")
             ops += [d.P2POp(d.isend, su, up), d.P2POp(d.isend, sv, up),
                     d.P2POp(d.irecv, ru, up), d.P2POp(d.irecv, rv, up)]
         if dn < self.world:  # my last owned rows become the top halo of the rank below
-            su, sv = self._bufs["send_dn"]
-            b.get_rows(self.top + (self.hi - self.lo) - h, su, sv)
-            ru, rv = self._bufs["recv_dn"]
+            b.get_rows(self.top + (self.hi - self.lo) - h, *self._bufs["send_dn"])
+            su, sv = out("send_dn")
+            ru, rv = inn("recv_dn")
             ops += [d.P2POp(d.isend, su, dn), d.P2POp(d.isend, sv, dn),
                     d.P2POp(d.irecv, ru, dn), d.P2POp(d.irecv, rv, dn)]
         if ops:
             for w in d.batch_isend_irecv(ops):
                 w.wait()
+        if host:
+            for name in ("recv_up", "recv_dn"):
+                if name in wire:
+                    self._bufs[name][0].copy_(wire[name][0])
+                    self._bufs[name][1].copy_(wire[name][1])
         if up >= 0:
-            ru, rv = self._bufs["recv_up"]
-            b.put_rows(0, ru, rv)                                   # rows [lo-halo, lo)
+            b.put_rows(0, *self._bufs["recv_up"])                               # rows [lo-halo, lo)
         if dn < self.world:
-            ru, rv = self._bufs["recv_dn"]
-            b.put_rows(self.top + (self.hi - self.lo), ru, rv)      # rows [hi, hi+halo)
+            b.put_rows(self.top + (self.hi - self.lo), *self._bufs["recv_dn"])  # rows [hi, hi+halo)
 
     def solve(self, lam, iters):
         """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchanges."""
