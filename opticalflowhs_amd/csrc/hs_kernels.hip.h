@@ -48,9 +48,23 @@ __device__ __forceinline__ float alpha_of(float Ix, float Iy, float ilambda)
     return 1.0f / (ilambda + q);
 }
 
-// One Jacobi update.  Factored form: with p = (Ix*ub + Iy*vb + It)*a,
-// u' = ub - Ix*p and v' = vb - Iy*p, which equals ub - (Ix^2*ub + Ix*Iy*vb + Ix*It)*a in exact
-// arithmetic (the oracle's record products are exact).
+// Per-pixel coefficients of the sweep, derived once per launch from the packed derivatives:
+//   al = Ix*s, be = Iy*s, ga = It*s   with   s = sqrt(alpha)      (sqrt correctly rounded)
+// so that the oracle's update  u' = ub - Ix*(Ix*ub + Iy*vb + It)*alpha  becomes
+//   q = al*ub + be*vb + ga,   u' = ub - al*q,   v' = vb - be*q
+// -- the same linear map with the factor alpha split evenly over its two uses: three registers
+// and four fused multiply-adds per pixel instead of four registers and five operations.
+__device__ __forceinline__ void sweep_coefs(uint32_t c, float ilambda, float &al, float &be, float &ga)
+{
+    float Ix, Iy, It;
+    unpack_deriv(c, Ix, Iy, It);
+    const float s = sqrtf(alpha_of(Ix, Iy, ilambda));
+    al = Ix * s;
+    be = Iy * s;
+    ga = It * s;
+}
+
+// One Jacobi update in the form above.
 //
 // Canonical order of the 4-neighbour sum (every kernel uses it, so all variants agree bit for bit):
 //   even image column:  ((R + (U + D)) + L) * 0.25      odd column:  ((L + (U + D)) + R) * 0.25
@@ -59,16 +73,16 @@ __device__ __forceinline__ float alpha_of(float Ix, float Iy, float ilambda)
 // which the reflection halo of the strip kernel needs.
 template <int ODD>
 __device__ __forceinline__ void update_cv(float uL, float uR, float uU, float uD, float vL,
-                                          float vR, float vU, float vD, float Ix, float Iy,
-                                          float It, float a, float &un, float &vn)
+                                          float vR, float vU, float vD, float al, float be,
+                                          float ga, float &un, float &vn)
 {
     const float su = ODD ? ((uL + (uU + uD)) + uR) : ((uR + (uU + uD)) + uL);
     const float sv = ODD ? ((vL + (vU + vD)) + vR) : ((vR + (vU + vD)) + vL);
     const float ub = su * 0.25f;
     const float vb = sv * 0.25f;
-    const float p = __fmaf_rn(Ix, ub, __fmaf_rn(Iy, vb, It)) * a;
-    un = __fmaf_rn(-Ix, p, ub);
-    vn = __fmaf_rn(-Iy, p, vb);
+    const float q = __fmaf_rn(al, ub, __fmaf_rn(be, vb, ga));
+    un = __fmaf_rn(-al, q, ub);
+    vn = __fmaf_rn(-be, q, vb);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -199,14 +213,13 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
         float nu[4], nv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            float Ix, Iy, It;
-            unpack_deriv(cc[k], Ix, Iy, It);
-            const float a = alpha_of(Ix, Iy, ilambda);
+            float al, be, ga;
+            sweep_coefs(cc[k], ilambda, al, be, ga);
             // replicate border: the last image column is its own right neighbour
             const bool last = (x0 + k >= W - 1);
             const float uR = last ? wu[k + 1] : wu[k + 2], vR = last ? wv[k + 1] : wv[k + 2];
-            if (k & 1) update_cv<1>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], Ix, Iy, It, a, nu[k], nv[k]);
-            else update_cv<0>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], Ix, Iy, It, a, nu[k], nv[k]);
+            if (k & 1) update_cv<1>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]);
+            else update_cv<0>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]);
             if (EPS && x0 + k < W)
                 e = fmaxf(e, fmaxf(fabsf(wu[k + 1] - nu[k]), fabsf(wv[k + 1] - nv[k])));
         }
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
     int go[K];           // global element offset (within the pair) of the group's first pixel
     unsigned fl[K];      // F_* flags
     float4 cu[K], cv[K]; // the group's own flow, current sweep
-    float cIx[K][4], cIy[K][4], cIt[K][4], cA[K][4];
+    float cAl[K][4], cBe[K][4], cGa[K][4];
 
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -326,8 +339,7 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                 const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    unpack_deriv(cc[p], cIx[k][p], cIy[k][p], cIt[k][p]);
-                    cA[k][p] = alpha_of(cIx[k][p], cIy[k][p], ilambda);
+                    sweep_coefs(cc[p], ilambda, cAl[k][p], cBe[k][p], cGa[k][p]);
                 }
             }
         }
@@ -359,10 +371,10 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                 if (f & F_GL) { uL = cu[k].x; vL = cv[k].x; }        // replicate: column 0 is its own left
                 if (pr == 3) { uR = cu[k].w; vR = cv[k].w; }          // replicate: column W-1 is its own right
                 float nu[4], nv[4];
-                update_cv<0>(uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cIx[k][0], cIy[k][0], cIt[k][0], cA[k][0], nu[0], nv[0]);
-                update_cv<1>(cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cIx[k][1], cIy[k][1], cIt[k][1], cA[k][1], nu[1], nv[1]);
-                update_cv<0>(cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cIx[k][2], cIy[k][2], cIt[k][2], cA[k][2], nu[2], nv[2]);
-                update_cv<1>(cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cIx[k][3], cIy[k][3], cIt[k][3], cA[k][3], nu[3], nv[3]);
+                update_cv<0>(uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cAl[k][0], cBe[k][0], cGa[k][0], nu[0], nv[0]);
+                update_cv<1>(cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cAl[k][1], cBe[k][1], cGa[k][1], nu[1], nv[1]);
+                update_cv<0>(cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cAl[k][2], cBe[k][2], cGa[k][2], nu[2], nv[2]);
+                update_cv<1>(cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cAl[k][3], cBe[k][3], cGa[k][3], nu[3], nv[3]);
                 if (EPS && (f & F_CORE)) { // columns > pr lie outside the image
                     e = fmaxf(e, fmaxf(fabsf(cu[k].x - nu[0]), fabsf(cv[k].x - nv[0])));
                     if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(cu[k].y - nu[1]), fabsf(cv[k].y - nv[1])));
@@ -458,7 +470,7 @@ __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, 
 // arithmetic step except the four side-neighbour additions is a packed (2 pixels per
 // instruction) v_pk_add/mul/fma_f32.  Summation order = the canonical one of update_cv<>:
 //   p0: ((p1 + (U+D)) + left)   p1: ((p0 + (U+D)) + p2)   p2: ((p3 + (U+D)) + p1)   p3: ((p2 + (U+D)) + right)
-struct RowCoef { f2 IxP, IxQ, IyP, IyQ, ItP, ItQ, aP, aQ; };
+struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
 
 __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const f2 upuP, const f2 upuQ,
                                                  const f2 upvP, const f2 upvQ, const f2 dnuP, const f2 dnuQ,
@@ -481,12 +493,12 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     sQ.y += wave_from_next_lane(vP.x);
     const f2 vbP = sP * 0.25f, vbQ = sQ * 0.25f;
     // update
-    const f2 pP = f2_fma(c.IxP, ubP, f2_fma(c.IyP, vbP, c.ItP)) * c.aP;
-    const f2 pQ = f2_fma(c.IxQ, ubQ, f2_fma(c.IyQ, vbQ, c.ItQ)) * c.aQ;
-    uP = f2_fma(-c.IxP, pP, ubP);
-    vP = f2_fma(-c.IyP, pP, vbP);
-    uQ = f2_fma(-c.IxQ, pQ, ubQ);
-    vQ = f2_fma(-c.IyQ, pQ, vbQ);
+    const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
+    const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
+    uP = f2_fma(-c.alP, qP, ubP);
+    vP = f2_fma(-c.beP, qP, vbP);
+    uQ = f2_fma(-c.alQ, qQ, ubQ);
+    vQ = f2_fma(-c.beQ, qQ, vbQ);
 }
 
 template <int R, int NTMAX, bool EPS>
@@ -583,17 +595,13 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         const uint4 cw = lc[r];
         uP[r] = f2{lu_.x, lu_.y}; uQ[r] = f2{lu_.z, lu_.w};
         vP[r] = f2{lv_.x, lv_.y}; vQ[r] = f2{lv_.z, lv_.w};
-        float Ix[4], Iy[4], It[4], a[4];
+        float al[4], be[4], ga[4];
         const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            unpack_deriv(cc[p], Ix[p], Iy[p], It[p]);
-            a[p] = alpha_of(Ix[p], Iy[p], ilambda);
-        }
-        cf[r].IxP = f2{Ix[0], Ix[1]}; cf[r].IxQ = f2{Ix[2], Ix[3]};
-        cf[r].IyP = f2{Iy[0], Iy[1]}; cf[r].IyQ = f2{Iy[2], Iy[3]};
-        cf[r].ItP = f2{It[0], It[1]}; cf[r].ItQ = f2{It[2], It[3]};
-        cf[r].aP = f2{a[0], a[1]};    cf[r].aQ = f2{a[2], a[3]};
+        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
+        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
+        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
+        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
     }
     // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
     unsigned rowcore = 0;
@@ -821,17 +829,13 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
     for (int r = 0; r < R; r++) {
         uP[r] = f2{lu[r].x, lu[r].y}; uQ[r] = f2{lu[r].z, lu[r].w};
         vP[r] = f2{lv[r].x, lv[r].y}; vQ[r] = f2{lv[r].z, lv[r].w};
-        float Ix[4], Iy[4], It[4], a[4];
+        float al[4], be[4], ga[4];
         const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            unpack_deriv(cc[p], Ix[p], Iy[p], It[p]);
-            a[p] = alpha_of(Ix[p], Iy[p], ilambda);
-        }
-        cf[r].IxP = f2{Ix[0], Ix[1]}; cf[r].IxQ = f2{Ix[2], Ix[3]};
-        cf[r].IyP = f2{Iy[0], Iy[1]}; cf[r].IyQ = f2{Iy[2], Iy[3]};
-        cf[r].ItP = f2{It[0], It[1]}; cf[r].ItQ = f2{It[2], It[3]};
-        cf[r].aP = f2{a[0], a[1]};    cf[r].aQ = f2{a[2], a[3]};
+        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
+        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
+        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
+        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
     }
     // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
     unsigned rowcore = 0;

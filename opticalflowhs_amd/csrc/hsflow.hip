@@ -205,29 +205,38 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 
 // ------------------------------------------------------------------------------------------
 // Planner for the strip kernel: rows per lane R and wavefronts per workgroup NW.
-// Register budget fixes the wavefronts a SIMD can hold: R <= 4 -> 4, R = 5 -> 3, R <= 8 -> 2.
+// Register budget fixes the wavefronts a SIMD can hold: R <= 5 -> 4, R = 6 -> 3, R <= 8 -> 2.
 // ------------------------------------------------------------------------------------------
-int strip_max_waves(int R) { return R <= 4 ? 16 : (R <= 5 ? 12 : 8); }
 
 // Cost model (shader cycles at ~2.2 GHz), fitted to in-kernel phase stamps on MI355X at 1080p
 // (tools/stamps.py; profiles/): one launch = fixed launch/drain gap + per round [tile load +
 // T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
+int strip_max_waves(int R, int fold) { const int r = fold ? R + 1 : R; return r <= 5 ? 16 : (r <= 6 ? 12 : 8); }
+
 double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, int *wg_per_cu_out = nullptr)
 {
-    const int per_simd = R <= 4 ? 4 : (R <= 5 ? 3 : 2);
+    // Parameters fitted (least squares on log time) to profiles/r01_sweep_1080p_strip4.csv and
+    // profiles/r01_sweep_4k.csv; the sweep is VALU-issue bound at ~4.4 cycles per wave64 instruction
+    // per SIMD with 4 resident wavefronts (more with fewer), ~36 instructions per row per wavefront.
+    const int per_simd = strip_max_waves(R, fold) / 4;
     const int lds = NW * (fold ? 4096 : 8192);
     const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
     if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
     const long long slots = (long long)kNumCU * wg_per_cu;
-    const long long rounds = (tiles + slots - 1) / slots;
     const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // WGs sharing a CU
     const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
-    const double row_cycles = wps >= 3.5 ? 35.0 * wps : (wps >= 2.5 ? 50.0 * wps : 85.0 * std::max(wps, 1.0));
-    const double compute = R * row_cycles;
-    const double exchange = 480.0 + (fold ? 30.0 : 46.0) * NW * conc + (fold ? 120.0 : 0.0);
-    const double sweep = 1.5 * (compute + exchange);
-    const double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
-    return 8800.0 + (double)rounds * (load + T * sweep);
+    const double cpi = wps >= 3.5 ? 4.4 : (wps >= 2.5 ? 5.6 : (wps >= 1.5 ? 7.5 : 8.0));
+    const int rows_per_lane = fold ? 2 * R : R;
+    const double halo_frac = std::min(1.0, 2.0 * T / (double)(NW * rows_per_lane));
+    const double instr_per_row = fold ? 42.0 : 34.0;
+    const double valu = std::max(wps, 1.0) * R * instr_per_row * cpi * (1.0 - 0.45 * halo_frac);
+    const double exchange = 300.0 + (fold ? 18.0 : 30.0) * NW * conc;
+    const double sweep = valu + exchange;
+    double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
+    if (conc > 1) load *= 0.6; // another workgroup's sweeps hide part of it
+    const double r = (double)tiles / (double)slots;
+    const double rounds = conc == 1 ? std::ceil(r) : std::max(1.0, r + 0.7);
+    return 11000.0 + rounds * (load + T * sweep);
 }
 
 bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold, StripPlan &best, double *cost_out = nullptr)
@@ -240,7 +249,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
     bool found = false;
     for (int R = 1; R <= 8; R++) {
         if (rows && rows != R) continue;
-        for (int NW = 1; NW <= strip_max_waves(R); NW++) {
+        for (int NW = 1; NW <= strip_max_waves(R, fold); NW++) {
             if (threads && threads != NW * 64) continue;
             const int CH = NW * R * (fold ? 2 : 1) - 2 * T;
             if (CH < 1) continue;
@@ -312,8 +321,8 @@ hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *
     case 2: return launch_strip_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 3: return launch_strip_t<3, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 4: return launch_strip_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 5: return launch_strip_t<5, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 6: return launch_strip_t<6, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5: return launch_strip_t<5, FOLD ? 768 : 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 6: return launch_strip_t<6, FOLD ? 512 : 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 7: return launch_strip_t<7, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 8: return launch_strip_t<8, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     }

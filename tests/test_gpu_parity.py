@@ -125,7 +125,7 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
                  dict(kernel=hs.KERNEL_FUSED, fuse_steps=7, tile_w=204, tile_h=7),
                  dict(kernel=hs.KERNEL_FUSED, fuse_steps=5, use_graph=True),
                  dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, use_graph=True)]
-    for T, R, nt in ((1, 1, 256), (2, 2, 192), (3, 3, 1024), (4, 4, 1024), (5, 5, 768), (7, 6, 512), (9, 7, 512),
+    for T, R, nt in ((1, 1, 256), (2, 2, 192), (3, 3, 1024), (4, 4, 1024), (5, 5, 1024), (7, 6, 768), (9, 7, 512),
                      (12, 8, 512), (8, 3, 640), (30, 8, 512), (6, 1, 1024)):
         variants.append(dict(kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=nt))
     variants += [dict(kernel=hs.KERNEL_FOLD), dict(kernel=hs.KERNEL_FOLD, use_graph=True)]

@@ -52,7 +52,7 @@ def main():
     for T in [int(x) for x in args.fuse.split(",") if x]:
         for R in [int(x) for x in args.strip.split(",") if x]:
             for NW in [int(x) for x in args.waves.split(",") if x]:
-                if NW * R - 2 * T < 1 or NW > (16 if R <= 4 else 12 if R == 5 else 8):
+                if NW * R - 2 * T < 1 or NW > (16 if R <= 5 else 12 if R == 6 else 8):
                     continue
                 variants.append(("S_T%d_R%d_NW%d" % (T, R, NW),
                                  dict(kernel=hs.KERNEL_STRIP, fuse_steps=T, strip_rows=R, threads=NW * 64)))

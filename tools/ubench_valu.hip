@@ -3,6 +3,7 @@
 // build: hipcc -O3 --offload-arch=gfx950 -o ubench_valu tools/ubench_valu.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 
 #define REP16(x) x x x x x x x x x x x x x x x x
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, int iters)
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
-    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-    if (s == 12345.678f) out[0] = 0; // keep the values alive
+    // every wavefront reports; the host takes the slowest one of the block (the SIMD arbiter favours
+    // the oldest wavefront, so wavefront 0 alone would under-state the cost)
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+    if (s == 12345.678f) out[blockIdx.x * 16] = 0; // keep the values alive
 }
 
 template <int OP>
@@ -77,10 +80,15 @@ void run(const char *name, unsigned long long *d)
         hipDeviceSynchronize();
         hipLaunchKernelGGL(k<OP>, dim3(256), dim3(threads), 0, 0, d, iters);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h(256);
-        hipMemcpy(h.data(), d, 256 * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h(256 * 16);
+        hipMemcpy(h.data(), d, 256 * 16 * 8, hipMemcpyDeviceToHost);
         double s = 0;
-        for (auto v : h) s += (double)v;
+        const int nw = threads / 64;
+        for (int b = 0; b < 256; b++) {
+            unsigned long long m = 0;
+            for (int w = 0; w < nw; w++) m = std::max(m, h[b * 16 + w]);
+            s += (double)m;
+        }
         s /= 256;
         // cycles per instruction per SIMD = elapsed / (instructions issued on that SIMD)
         printf("  %dw/SIMD: %.2f cyc/instr", waves_per_simd, s / (n * waves_per_simd));
@@ -91,7 +99,7 @@ void run(const char *name, unsigned long long *d)
 int main()
 {
     unsigned long long *d;
-    hipMalloc(&d, 256 * 8);
+    hipMalloc(&d, 256 * 16 * 8);
     run<5>("v_add_f32", d);
     run<0>("v_fma_f32", d);
     run<7>("v_mov_b32", d);
