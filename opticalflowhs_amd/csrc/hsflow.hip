@@ -213,11 +213,12 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 // T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
 int strip_max_waves(int R, int fold) { const int r = fold ? R + 1 : R; return r <= 5 ? 16 : (r <= 6 ? 12 : 8); }
 
-double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, int *wg_per_cu_out = nullptr)
+double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double image_pixels, int *wg_per_cu_out = nullptr)
 {
-    // Parameters fitted (least squares on log time) to profiles/r01_sweep_1080p_strip4.csv and
-    // profiles/r01_sweep_4k.csv; the sweep is VALU-issue bound at ~4.4 cycles per wave64 instruction
-    // per SIMD with 4 resident wavefronts (more with fewer), ~36 instructions per row per wavefront.
+    // Parameters fitted (least squares on log time, rms 8 %) to profiles/r01_sweep_1080p_strip5.csv,
+    // r01_sweep_4k_b.csv and r01_sweep_batch16.csv.  The sweep is VALU-issue bound (~34 instructions
+    // per row per wavefront, ~4.2 cycles each per SIMD with 4 resident wavefronts, more with fewer);
+    // a launch boundary costs ~2.7 us plus the L2 write-back of the 8 bytes per pixel just stored.
     const int per_simd = strip_max_waves(R, fold) / 4;
     const int lds = NW * (fold ? 4096 : 8192);
     const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
@@ -225,18 +226,18 @@ double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, int *w
     const long long slots = (long long)kNumCU * wg_per_cu;
     const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // WGs sharing a CU
     const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
-    const double cpi = wps >= 3.5 ? 4.4 : (wps >= 2.5 ? 5.6 : (wps >= 1.5 ? 7.5 : 8.0));
+    const double cpi = wps >= 3.5 ? 4.2 : (wps >= 2.5 ? 5.6 : (wps >= 1.5 ? 6.5 : 8.0));
     const int rows_per_lane = fold ? 2 * R : R;
     const double halo_frac = std::min(1.0, 2.0 * T / (double)(NW * rows_per_lane));
     const double instr_per_row = fold ? 42.0 : 34.0;
     const double valu = std::max(wps, 1.0) * R * instr_per_row * cpi * (1.0 - 0.45 * halo_frac);
-    const double exchange = 300.0 + (fold ? 18.0 : 30.0) * NW * conc;
+    const double exchange = 300.0 + (fold ? 12.0 : 20.0) * NW * conc;
     const double sweep = valu + exchange;
     double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
-    if (conc > 1) load *= 0.6; // another workgroup's sweeps hide part of it
+    if (conc > 1) load *= 0.4; // another workgroup's sweeps hide part of it
     const double r = (double)tiles / (double)slots;
     const double rounds = conc == 1 ? std::ceil(r) : std::max(1.0, r + 0.7);
-    return 11000.0 + rounds * (load + T * sweep);
+    return 6000.0 + 6e-4 * 8.0 * image_pixels + rounds * (load + T * sweep);
 }
 
 bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold, StripPlan &best, double *cost_out = nullptr)
@@ -257,7 +258,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
-            const double cost = strip_launch_cost(T, R, NW, tiles, fold);
+            const double cost = strip_launch_cost(T, R, NW, tiles, fold, (double)W * H * c->N);
             if (cost < best_cost - 1e-9) {
                 best_cost = cost;
                 found = true;
