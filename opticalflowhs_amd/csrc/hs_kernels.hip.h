@@ -712,10 +712,15 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         for (int r = 0; r < R; r++) {
             if ((rowcore >> r) & 1u) {
                 const long long off = base + (long long)(y0 + r) * g.P + x0;
-#ifdef HS_EXP_NT_STORE /* experiment: write-through stores, nothing left dirty in L2 at kernel end */
+#if defined(HS_EXP_NT_STORE) /* experiment (slower): non-temporal stores */
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, (v4f *)(u_out + off));
                 __builtin_nontemporal_store(v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y}, (v4f *)(v_out + off));
+#elif defined(HS_EXP_SC1_STORE) /* experiment: agent-scope write-through stores (nothing dirty at kernel end) */
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f su_ = v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, sv_ = v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(u_out + off), "v"(su_) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(v_out + off), "v"(sv_) : "memory");
 #else
                 *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
                 *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
