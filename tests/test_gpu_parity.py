@@ -302,3 +302,22 @@ def test_large_frame_size_independent_properties(hs, gpu_ok):
     assert np.array_equal(u8, u1) and np.array_equal(v8, v1)
     uf, vf, _ = gpu_solve(hs, np.ascontiguousarray(A[:, ::-1]), np.ascontiguousarray(B[:, ::-1]), 1.0, 24)
     assert rms(uf, -u8[:, ::-1]) < 1e-5 and rms(vf, v8[:, ::-1]) < 1e-5
+
+
+def test_full_16384_frame_bands_against_oracle(hs, oracle, gpu_ok):
+    """BASELINE config C5 at its full size on one GPU (268 Mpixel, 5.9 GB of planes): 8 sweeps, then
+    three row bands (top border, middle, bottom border) are compared with the oracle run on the band
+    plus a 16-row margin -- exact for the band because 8 sweeps cannot carry the margin's artificial
+    border further than 8 rows."""
+    W = H = 16384
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (H // 8 + 2, W // 8 + 2), dtype=np.uint8)
+    A = np.repeat(np.repeat(base, 8, axis=0), 8, axis=1)[3:3 + H, 5:5 + W].copy()   # blocky texture, cheap to make
+    B = np.roll(A, (1, 2), axis=(0, 1))
+    B[::7, ::5] += 3
+    u, v, info = gpu_solve(hs, A, B, 1.0, 8)
+    assert info["iterations_done"] == 8 and np.isfinite(u).all() and np.isfinite(v).all()
+    for lo, hi in ((0, 40), (8000, 8040), (H - 40, H)):
+        a, b = max(0, lo - 16), min(H, hi + 16)
+        uo, vo = oracle.calc_optical_flow_hs(A[a:b], B[a:b], 1.0, 8, term_type=ITER, threads=0)
+        check("c5_full_band_%d" % lo, (u[lo:hi], v[lo:hi]), (uo[lo - a:hi - a], vo[lo - a:hi - a]))
