@@ -87,7 +87,7 @@ def load():
         pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            "opticalflowhs_amd: %s is missing -- build it with `python -m opticalflowhs_amd.build` "
+            "opticalflowhs_amd: %s is missing -- build it with `python opticalflowhs_amd/build.py` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
     try:
         lib = ctypes.CDLL(LIB_PATH)
