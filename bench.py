@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--iter-eps", action="store_true",
+                    help="time the reference's own call form ITER|EPS (eps 1e-6) instead of ITER only (synchronous solves)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0: same as --iters)")
     return ap.parse_args()
@@ -108,15 +110,22 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.iter_eps:  # the early-stop check needs one read-back per solve: synchronous, no graph
+        p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER | hs.TERM_EPS,
+                            epsilon=float(np.float32(1e-6)), kernel=kernel, fuse_steps=args.fuse_steps,
+                            tile_w=args.tile_w, tile_h=args.tile_h, threads=args.threads, strip_rows=args.strip_rows)
+        step = lambda: ctx.solve(p)
+    else:
+        step = lambda: ctx.solve_async(p)
     for _ in range(args.warmup):
-        ctx.solve_async(p)
+        step()
     torch.cuda.synchronize()
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.solve_async(p)
+        step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -161,7 +170,8 @@ def main():
                    "kernel": KNAME[info["kernel"]],
                    "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
                    "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
-                   "hipgraph": not args.no_graph, "sharding": "independent pairs per rank, no collective"},
+                   "hipgraph": (not args.no_graph) and not args.iter_eps,
+                   "termination": "ITER|EPS (eps 1e-6)" if args.iter_eps else "ITER", "sharding": "independent pairs per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_jacobi_" + KNAME[info["kernel"]],

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
                                                        unsigned *__restrict__ eps_out)
 {
     // ZERO: the incoming flow is identically zero (first sweep of a solve): nothing is read
+    // EPS: eps_out[0] receives max |new - old| of this sweep (atomicMax on the float's bit pattern)
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const bool active = (x0 < W) && (y < H);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                                                      float *__restrict__ u_out,
                                                      float *__restrict__ v_out, const FusedGeom g,
                                                      const float ilambda,
-                                                     unsigned *__restrict__ eps_out)
+                                                     unsigned *__restrict__ eps_out, const int eps_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *su = smem;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
         }
         if (EPS) {
             e = wave_max(e);
-            if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
+            if (lane == 0) atomicMax(eps_out + (size_t)s * eps_stride, __float_as_uint(e));
         }
         if (s == g.T - 1) break;
         __syncthreads(); // every LDS read of sweep s is done
@@ -508,18 +509,21 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         float *__restrict__ u_out,
                                                         float *__restrict__ v_out, const StripGeom g,
                                                         const float ilambda,
-                                                        unsigned *__restrict__ eps_out,
+                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps)
 {
+    // EPS: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over its
+    // core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
     // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
     // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
     // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hsflow.hip).
-    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64]
+    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64], then 32 floats for Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
     if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = g.NW;
+    float *eps_lds = (float *)(ex + (size_t)2 * NW * 4 * 64);
     const int tpp = g.tiles_x * g.tiles_y;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const int pair = tile / tpp;
@@ -695,13 +699,26 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
             }
         }
         if (R == 1 && s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
-        if (EPS) {
+        if (EPS) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
             e = wave_max(e);
-            if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
+            if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
+            if (s > 0 && w == 0) {
+                float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
+                x = wave_max(x);
+                if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+            }
         }
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (s + 1 < g.T) __syncthreads();
 #endif
+    }
+    if (EPS) {
+        __syncthreads();
+        if (w == 0) {
+            float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
+            x = wave_max(x);
+            if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+        }
     }
 #undef HS_ROW
 #undef HS_PUBLISH
@@ -767,16 +784,17 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        float *__restrict__ u_out,
                                                        float *__restrict__ v_out, const StripGeom g,
                                                        const float ilambda,
-                                                       unsigned *__restrict__ eps_out,
+                                                       unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32]
+    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
     if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const bool lower = lane >= 32;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = g.NW;
+    float *eps_lds = (float *)(ex + (size_t)2 * NW * 2 * 2 * 32);
     const int tpp = g.tiles_x * g.tiles_y;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const int pair = tile / tpp;
@@ -921,9 +939,22 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
         }
         if (EPS) {
             e = wave_max(e);
-            if (lane == 0) atomicMax(eps_out + s, __float_as_uint(e));
+            if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
+            if (s > 0 && w == 0) {
+                float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
+                x = wave_max(x);
+                if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+            }
         }
         if (s + 1 < g.T) __syncthreads();
+    }
+    if (EPS) {
+        __syncthreads();
+        if (w == 0) {
+            float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
+            x = wave_max(x);
+            if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+        }
     }
 #undef HF_ROW
 #undef HF_PUBLISH
@@ -949,6 +980,21 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
         o[7] = (unsigned long long)tile;
     }
+}
+
+// Eps of every sweep = maximum over that sweep's row of per-workgroup values (bit patterns of
+// non-negative floats order like unsigned integers).  One workgroup per sweep.
+__global__ __launch_bounds__(256) void k_eps_reduce(const unsigned *__restrict__ tiles, int stride,
+                                                    unsigned *__restrict__ out)
+{
+    __shared__ unsigned part[4];
+    const unsigned *row = tiles + (size_t)blockIdx.x * stride;
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < stride; i += 256) m = max(m, row[i]);
+    float f = wave_max(__uint_as_float(m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __float_as_uint(f);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
 } // namespace hsk

@@ -78,6 +78,13 @@ struct hsflow_ctx {
     float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
     unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
     unsigned *dEps = nullptr;   // kMaxFuse words
+    unsigned *epsPtr = nullptr; // where the running launch records Eps: [sweep][epsStride] words
+    int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
+    unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
+    size_t epsTilesCap = 0;
+    unsigned *dEpsAll = nullptr; // one word per sweep of a whole ITER|EPS solve (speculative run)
+    int epsAllCap = 0;
+    float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
     unsigned *hEps = nullptr;   // pinned mirror
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;
@@ -176,7 +183,7 @@ hipError_t launch_fused_t(const hsflow_ctx *c, const FusedPlan &p, const float *
     }
     if (configure_only) return hipSuccess; // done ahead of a stream capture
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dCoef, ui, vi, uo,
-                       vo, p.g, coeff, c->dEps);
+                       vo, p.g, coeff, c->epsPtr, c->epsStride);
     return hipGetLastError();
 }
 
@@ -254,7 +261,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
             if (threads && threads != NW * 64) continue;
             const int CH = NW * R * (fold ? 2 : 1) - 2 * T;
             if (CH < 1) continue;
-            const int lds = NW * (fold ? 4096 : 8192);
+            const int lds = NW * (fold ? 4096 : 8192) + 128; // edge-row exchange + 32 floats for Eps
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
@@ -309,7 +316,7 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
     }
     if (configure_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                       uo, vo, p.g, coeff, c->dEps, p.tiles <= 65536 ? c->dStamps : nullptr);
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr);
     return hipGetLastError();
 }
 
@@ -374,7 +381,7 @@ hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const f
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
 #define HS_SIMPLE(E, Z)                                                                            \
     hipLaunchKernelGGL((hsk::k_jacobi_simple<E, Z>), grid, block, 0, c->stream, c->dCoef, ui, vi, uo, vo, \
-                       c->W, c->H, c->P, c->plane, coeff, c->dEps)
+                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr)
     if (eps) { if (zero_in) HS_SIMPLE(true, true); else HS_SIMPLE(true, false); }
     else { if (zero_in) HS_SIMPLE(false, true); else HS_SIMPLE(false, false); }
 #undef HS_SIMPLE
@@ -477,6 +484,42 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
     (void)p;
     return HSFLOW_OK;
 }
+
+// Eps bookkeeping of an EPS-terminated solve: `sweeps` rows of `stride` words, cleared, plus the
+// reduction of the rows into dEpsAll[0..sweeps).
+int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
+{
+    const size_t need = (size_t)sweeps * stride;
+    if (c->epsTilesCap < need) {
+        hipFree(c->dEpsTiles);
+        c->dEpsTiles = nullptr; c->epsTilesCap = 0;
+        HS_HIP(c, hipMalloc((void **)&c->dEpsTiles, need * sizeof(unsigned)));
+        c->epsTilesCap = need;
+    }
+    if (c->epsAllCap < sweeps) {
+        hipFree(c->dEpsAll);
+        c->dEpsAll = nullptr; c->epsAllCap = 0;
+        HS_HIP(c, hipMalloc((void **)&c->dEpsAll, (size_t)sweeps * sizeof(unsigned)));
+        c->epsAllCap = sweeps;
+    }
+    HS_HIP(c, hipMemsetAsync(c->dEpsTiles, 0, need * sizeof(unsigned), c->stream));
+    c->epsStride = stride;
+    return HSFLOW_OK;
+}
+
+int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
+{
+    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
+    HS_HIP(c, hipGetLastError());
+    host.resize((size_t)sweeps);
+    HS_HIP(c, hipMemcpyAsync(host.data(), c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    c->epsPtr = c->dEps;
+    c->epsStride = 1;
+    return HSFLOW_OK;
+}
+
+int plan_eps_stride(int kernel, const JPlan &pl) { return (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) ? pl.s.tiles : 1; }
 
 // Diagnostic only: with HSFLOW_DEBUG_STAMPS=<file> every strip launch records per-workgroup phase
 // stamps (8 x u64) and hsflow_solve appends those of the LAST launch to <file> as text.
@@ -594,7 +637,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         const int horizon = budget > (1 << 30) ? 64 : (int)budget; // EPS-only runs: plan for chunks
         if (p.fuse_steps > 0) T = std::min(p.fuse_steps, kMaxFuse);
         else if (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)
-            T = use_eps ? std::min(8, horizon) : pick_strip_T(c, horizon, p, kernel == HSFLOW_KERNEL_FOLD);
+            T = (use_eps && !(use_iter && p.max_iter > 0)) ? std::min(8, horizon)
+                                                          : pick_strip_T(c, horizon, p, kernel == HSFLOW_KERNEL_FOLD);
         else T = pick_T(horizon, 0);
         if (budget < T) T = (int)budget;
         if (!make_jplan(c, kernel, T, p, plan))
@@ -660,7 +704,92 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         return HSFLOW_OK;
     }
 
-    // EPS termination (CvTermCriteria with CV_TERMCRIT_EPS): Eps_k = max |u_k - u_{k-1}|, |v_k - v_{k-1}|
+    // ITER|EPS -- the way the reference calls the solver (OpticalFlowOpenCV.cpp:29).  On real image
+    // pairs Eps never drops below 1e-6 within the sweep budget, so the budget is run SPECULATIVELY at
+    // full speed (no host round trip between launches) while every sweep records its Eps on the device;
+    // one read-back at the end finds the first sweep k with Eps_k < epsilon.  If there is none the
+    // result stands; otherwise exactly k sweeps are re-run from the saved starting flow, which
+    // reproduces the oracle's stopping sweep.
+    constexpr long long kSpecMax = 1 << 16;
+    if (use_iter && p.max_iter > 0 && budget <= kSpecMax) {
+        const int iters = (int)budget;
+        const size_t px = (size_t)c->plane * c->N;
+        if (p.use_previous) { // keep the starting flow: the ping-pong buffers get overwritten
+            if (!c->dUb) HS_HIP(c, hipMalloc((void **)&c->dUb, px * sizeof(float)));
+            if (!c->dVb) HS_HIP(c, hipMalloc((void **)&c->dVb, px * sizeof(float)));
+            HS_HIP(c, hipMemcpyAsync(c->dUb, c->dU[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HS_HIP(c, hipMemcpyAsync(c->dVb, c->dV[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        // every launch of this solve uses the same number of workgroups or fewer (tail): stride = max
+        int stride = multi ? plan_eps_stride(kernel, plan) : 1;
+        if (multi && iters % T) {
+            JPlan tp;
+            if (!make_jplan(c, kernel, iters % T, p, tp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+            stride = std::max(stride, plan_eps_stride(kernel, tp));
+        }
+        if ((st = eps_prepare(c, iters, stride))) return st;
+        if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
+            prof.begin(0);
+            HS_HIP(c, launch_deriv(c));
+            prof.end();
+        }
+        c->coef_valid = true;
+        c->coef_mode = HSFLOW_MODE_CV;
+        int zero_in = p.use_previous ? 0 : 1, launches = 0, done = 0;
+        if (zero_in) c->cur = 0;
+        while (done < iters) {
+            const int chunk = multi ? std::min(T, iters - done) : 1;
+            JPlan cp = plan;
+            if (multi && chunk != T && !make_jplan(c, kernel, chunk, p, cp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+            const int a = c->cur, b = a ^ 1;
+            c->epsPtr = c->dEpsTiles + (size_t)done * stride;
+            prof.begin(1);
+            hipError_t e = multi ? launch_j(c, cp, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in)
+                                 : launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, zero_in);
+            prof.end();
+            HS_HIP(c, e);
+            c->cur = b;
+            zero_in = 0;
+            done += chunk;
+            launches++;
+        }
+        std::vector<unsigned> heps;
+        if ((st = eps_collect(c, iters, heps))) return st;
+        int hit = -1;
+        float last = 0.f;
+        for (int s2 = 0; s2 < iters; s2++) {
+            std::memcpy(&last, &heps[(size_t)s2], sizeof(float));
+            if ((double)last < p.epsilon) { hit = s2; break; }
+        }
+        if (hit >= 0 && hit + 1 < iters) { // converged early: redo exactly hit+1 sweeps from the start
+            const int k = hit + 1;
+            if (p.use_previous) {
+                HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            }
+            JPlan kp, kt;
+            int Tk = 1;
+            if (multi) {
+                Tk = std::min(T, k);
+                if (!make_jplan(c, kernel, Tk, p, kp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the re-run");
+                if (k % Tk && !make_jplan(c, kernel, k % Tk, p, kt)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the re-run tail");
+            }
+            st = enqueue_fixed(c, p, coeff, k, kernel, Tk, &kp, &kt, prof, false, !p.use_previous);
+            if (st) return st;
+            launches += c->info.jacobi_launches;
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            c->info.iterations_done = k;
+        } else {
+            c->info.iterations_done = hit >= 0 ? hit + 1 : iters;
+        }
+        c->info.last_eps = last;
+        c->info.jacobi_launches = launches;
+        prof.collect();
+        return HSFLOW_OK;
+    }
+
+    // EPS without a usable sweep budget (CV_TERMCRIT_EPS alone): Eps_k = max |u_k - u_{k-1}|, |v_k - v_{k-1}|
     // is produced per sweep by the kernel; the host looks at it after every chunk and, if the
     // threshold was crossed inside the chunk, replays the chunk up to that sweep (its input buffer
     // is still intact), which reproduces the oracle's stopping sweep exactly.
@@ -686,7 +815,9 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         if (multi && chunk != T && !make_jplan(c, kernel, chunk, p, cp))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
         const int a = c->cur, b = a ^ 1;
-        HS_HIP(c, hipMemsetAsync(c->dEps, 0, kMaxFuse * sizeof(unsigned), c->stream));
+        const int n = multi ? chunk : 1;
+        if ((st = eps_prepare(c, n, multi ? plan_eps_stride(kernel, cp) : 1))) return st;
+        c->epsPtr = c->dEpsTiles;
         prof.begin(1);
         if (!multi)
             HS_HIP(c, launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
@@ -694,13 +825,12 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             HS_HIP(c, launch_j(c, cp, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
         prof.end();
         launches++;
-        HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEps, kMaxFuse * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HS_HIP(c, hipStreamSynchronize(c->stream));
-        const int n = multi ? chunk : 1;
+        std::vector<unsigned> heps;
+        if ((st = eps_collect(c, n, heps))) return st;
         int hit = -1;
         for (int s = 0; s < n; s++) {
             float e;
-            std::memcpy(&e, &c->hEps[s], sizeof(float));
+            std::memcpy(&e, &heps[(size_t)s], sizeof(float));
             last = e;
             if ((double)e < p.epsilon) { hit = s; break; }
         }
@@ -822,6 +952,7 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
         HS_TRY(hipMalloc((void **)&c->dV[i], px * sizeof(float)));
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
+    c->epsPtr = c->dEps;
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     HS_TRY(hipHostMalloc((void **)&c->hEps, kMaxFuse * sizeof(unsigned), hipHostMallocDefault));
     // deterministic contents for padding columns and the initial flow
@@ -852,6 +983,7 @@ int hsflow_destroy(hsflow_ctx *c)
     for (int i = 0; i < 3; i++) hipFree(c->dE[i]);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
+    hipFree(c->dEpsAll); hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
     if (c->hEps) hipHostFree(c->hEps);
     hipFree(c->dScratch);

@@ -160,6 +160,19 @@ def test_eps_termination_matches_oracle(hs, gpu_ok):
     # EPS only
     u2, v2, info2 = gpu_solve(hs, d["A"], d["B"], 0.002, 0, eps=1e-3, tt=EPS)
     assert abs(info2["iterations_done"] - int(d["iters"])) <= 1
+    # ITER|EPS continuing from a previous flow: 5 sweeps, then the rest with the early stop
+    with hs.HSFlow(48, 40, 1, own_stream=True) as ctx:
+        ctx.set_frames(d["A"], d["B"])
+        ctx.solve(lam=0.002, max_iter=5, term_type=ITER)
+        info3 = ctx.solve(lam=0.002, max_iter=495, epsilon=1e-3, term_type=ITER | EPS, use_previous=True)
+        u3, v3 = ctx.flow()
+    assert abs(info3["iterations_done"] + 5 - int(d["iters"])) <= 1
+    if info3["iterations_done"] + 5 == int(d["iters"]):
+        check("eps_stop_use_previous", (u3, v3), (d["u"], d["v"]))
+    # budget reached before the threshold: plain ITER result
+    u4, v4, info4 = gpu_solve(hs, d["A"], d["B"], 0.002, 40, eps=1e-3, tt=ITER | EPS)
+    u5, v5, _ = gpu_solve(hs, d["A"], d["B"], 0.002, 40, tt=ITER)
+    assert info4["iterations_done"] == 40 and np.array_equal(u4, u5) and np.array_equal(v4, v5)
 
 
 def test_use_previous_and_row_copies(hs, gpu_ok):
