@@ -77,7 +77,7 @@ struct hsflow_ctx {
     int coef_mode = -1;          // discretisation the current derivatives belong to
     float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
     unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
-    unsigned *dEps = nullptr;   // kMaxFuse words
+    unsigned *dEps = nullptr;   // kMaxFuse words: Eps sink of launches that do not collect it
     unsigned *epsPtr = nullptr; // where the running launch records Eps: [sweep][epsStride] words
     int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
     unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
@@ -85,7 +85,6 @@ struct hsflow_ctx {
     unsigned *dEpsAll = nullptr; // one word per sweep of a whole ITER|EPS solve (speculative run)
     int epsAllCap = 0;
     float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
-    unsigned *hEps = nullptr;   // pinned mirror
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;
     int cur = 0;                // which of dU/dV holds the current flow
@@ -95,7 +94,6 @@ struct hsflow_ctx {
     std::string err;
     std::map<GraphKey, GraphEntry> graphs;
     std::vector<hipEvent_t> events;
-    bool capturing = false;
 };
 
 namespace {
@@ -954,7 +952,6 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
     c->epsPtr = c->dEps;
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
-    HS_TRY(hipHostMalloc((void **)&c->hEps, kMaxFuse * sizeof(unsigned), hipHostMallocDefault));
     // deterministic contents for padding columns and the initial flow
     HS_TRY(hipMemsetAsync(c->dA, 0, px, c->stream));
     HS_TRY(hipMemsetAsync(c->dB, 0, px, c->stream));
@@ -985,7 +982,6 @@ int hsflow_destroy(hsflow_ctx *c)
     hipFree(c->dEps);
     hipFree(c->dEpsAll); hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
-    if (c->hEps) hipHostFree(c->hEps);
     hipFree(c->dScratch);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
