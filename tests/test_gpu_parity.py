@@ -334,3 +334,42 @@ def test_full_16384_frame_bands_against_oracle(hs, oracle, gpu_ok):
         a, b = max(0, lo - 16), min(H, hi + 16)
         uo, vo = oracle.calc_optical_flow_hs(A[a:b], B[a:b], 1.0, 8, term_type=ITER, threads=0)
         check("c5_full_band_%d" % lo, (u[lo:hi], v[lo:hi]), (uo[lo - a:hi - a], vo[lo - a:hi - a]))
+
+
+def test_randomized_shapes_parameters_kernels(hs, oracle, gpu_ok):
+    """Seeded random sweep over frame shapes (including images narrower than the halo, odd widths,
+    single rows / columns), lambda, sweep counts and every kernel with random tuning knobs: parity
+    with the oracle and bit equality between kernels."""
+    rng = np.random.default_rng(20261004)
+    kernels = [hs.KERNEL_SIMPLE, hs.KERNEL_FUSED, hs.KERNEL_STRIP, hs.KERNEL_FOLD]
+    for case in range(48):
+        W = int(rng.integers(1, 340)) if case % 5 else int(rng.integers(1, 12))
+        H = int(rng.integers(1, 260)) if case % 7 else int(rng.integers(1, 9))
+        lam = float(10.0 ** rng.uniform(-3, 2))
+        it = int(rng.integers(1, 64))
+        if case % 3 == 0:
+            A, B = synth.random_pair(W, H, seed=case)
+        else:
+            A, B = synth.translating_pair(W, H, seed=case, dx=float(rng.uniform(-2, 2)), dy=float(rng.uniform(-2, 2)))
+        uo, vo = oracle.calc_optical_flow_hs(A, B, lam, it, term_type=ITER)
+        ref = None
+        for k in kernels:
+            kw = dict(kernel=k)
+            if k == hs.KERNEL_FUSED:
+                kw["fuse_steps"] = int(rng.integers(1, 13))
+            elif k in (hs.KERNEL_STRIP, hs.KERNEL_FOLD):
+                T = int(rng.integers(1, 25))
+                R = int(rng.integers(1, 9))
+                fold = k == hs.KERNEL_FOLD
+                maxw = (16 if R <= 4 else 12 if R == 5 else 8) if fold else (16 if R <= 5 else 12 if R == 6 else 8)
+                need = -(-(2 * T + 1) // (R * (2 if fold else 1)))
+                if need > maxw:
+                    continue
+                kw.update(fuse_steps=T, strip_rows=R, threads=64 * int(rng.integers(need, maxw + 1)))
+            u, v, info = gpu_solve(hs, A, B, lam, it, **kw)
+            assert info["iterations_done"] == it
+            check("rnd%d_%dx%d_k%d" % (case, W, H, k), (u, v), (uo, vo))
+            if ref is None:
+                ref = (u, v)
+            else:
+                assert np.array_equal(u, ref[0]) and np.array_equal(v, ref[1]), (case, W, H, lam, it, kw)
