@@ -130,6 +130,11 @@ int hsflow_destroy(hsflow_ctx *ctx); /* NULL is accepted; idempotent per handle 
 /* Host u8 single-channel frames, row strides in bytes (>= width).  Synchronous. */
 int hsflow_set_frames_u8(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
                          const uint8_t *curr, size_t curr_stride);
+/* Same, but only enqueued on ctx's stream: the host buffers must stay valid and unchanged until
+ * the stream has passed the copy (hsflow_synchronize).  Truly asynchronous only from page-locked
+ * memory (hsflow_host_alloc / hsflow_host_register); from pageable memory HIP stages the copy. */
+int hsflow_set_frames_u8_async(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
+                               const uint8_t *curr, size_t curr_stride);
 /* Same, source already in device memory on ctx's device; enqueued on ctx's stream. */
 int hsflow_set_frames_u8_device(hsflow_ctx *ctx, int pair, const void *d_prev, size_t prev_stride,
                                 const void *d_curr, size_t curr_stride);
@@ -157,6 +162,9 @@ int hsflow_synchronize(hsflow_ctx *ctx);
 
 /* fp32 flow to host, row strides in bytes (multiple of 4, >= 4*width).  Synchronous. */
 int hsflow_get_flow(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, float *v, size_t v_stride);
+/* Same, only enqueued on ctx's stream (after the solve enqueued before it); u, v are complete
+ * after hsflow_synchronize.  Page-locked destination for a real overlap with other streams. */
+int hsflow_get_flow_async(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, float *v, size_t v_stride);
 /* Row range [row0, row0+nrows) of the flow to / from device memory, on ctx's stream (used for
  * the row-slab halo exchange).  set_ writes into the flow the next
  * use_previous=1 solve continues from. */
@@ -178,6 +186,40 @@ const char *hsflow_last_error(hsflow_ctx *ctx); /* ctx may be NULL: last create(
 const char *hsflow_status_string(int status);
 int hsflow_version(void); /* major*1000 + minor */
 int hsflow_device_count(int *count);
+
+/* --- page-locked host memory (staging for the async copies) ------------------------------- */
+
+/* The reference aliased host planes into the device with CL_MEM_USE_HOST_PTR
+ * (HSOpticalFlowOpenCL.cpp:184-228); here the caller keeps ownership of its host buffers and may
+ * page-lock them so that uploads / downloads overlap the solver. */
+int hsflow_host_alloc(void **out, size_t bytes);   /* hipHostMalloc */
+int hsflow_host_free(void *p);                     /* NULL accepted */
+int hsflow_host_register(void *p, size_t bytes);   /* page-lock memory the caller allocated */
+int hsflow_host_unregister(void *p);
+
+/* --- pair pipeline: host frames in, host flow out, copies overlapped with solves ----------- */
+
+/* Independent pairs streamed through ONE device (BASELINE config C4, SURVEY.md 8e: "one host
+ * thread + >= 2 streams per GPU, double-buffered staging").  The pipeline owns `depth` single-pair
+ * contexts, each on its own stream; submit() enqueues upload -> solve -> download of one pair on
+ * the next slot and returns at once, so that the upload of pair i+1 and the download of pair i-1
+ * run beside the solve of pair i.  It replaces the per-pair body of the reference's run()
+ * (HSOpticalFlowOpenCL.cpp:744-767: write frames, derivatives, iterations, read u, v).
+ * The host buffers of a submitted pair belong to the pipeline until wait(ticket) returned; use
+ * page-locked memory for them.  ITER-only termination (what hsflow_solve_async accepts).
+ * Single-owner like a context; one pipeline per (thread, device). */
+typedef struct hsflow_pipeline hsflow_pipeline;
+int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int height, int depth);
+int hsflow_pipeline_destroy(hsflow_pipeline *pl); /* drains first; NULL accepted */
+/* ticket (optional out): 0, 1, 2, ... in submission order.  Blocks only while the slot it is
+ * about to reuse (ticket - depth) is still running. */
+int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t prev_stride,
+                           const uint8_t *curr, size_t curr_stride, float *u, size_t u_stride,
+                           float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
+int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket); /* u, v of that pair are complete */
+int hsflow_pipeline_drain(hsflow_pipeline *pl);                 /* wait for everything submitted */
+int hsflow_pipeline_depth(hsflow_pipeline *pl);
+const char *hsflow_pipeline_last_error(hsflow_pipeline *pl);    /* pl may be NULL: create() error */
 
 /* --- one-shot ------------------------------------------------------------------------------ */
 

@@ -1,15 +1,16 @@
 """opticalflowhs_amd -- MI355X-native Horn-Schunck optical flow (hot path of miczi/OpticalFlowHS).
 
 Layout: csrc/ holds the HIP kernels and the C ABI (include/hsflow.h); solver.py is the host-side
-mirror of the reference interface; slab.py / batch.py are the multi-GPU drivers.  The package has
+mirror of the reference interface; pipeline.py streams pairs through one GPU with overlapped copies, slab.py is the multi-GPU row-slab driver.  The package has
 no CPU fallback: importing it without libhsflow.so raises.
 """
 from . import _lib
 from ._lib import (HsflowError, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD, MODE_CLASSIC, MODE_CV,
                    TERM_EPS, TERM_ITER)
-from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, term_criteria
+from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, make_params, term_criteria
+from .pipeline import PairPipeline, pinned_empty
 
-__all__ = ["HSFlow", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
+__all__ = ["HSFlow", "PairPipeline", "pinned_empty", "make_params", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
            "TERM_ITER", "TERM_EPS", "MODE_CV", "MODE_CLASSIC", "KERNEL_AUTO", "KERNEL_SIMPLE",
            "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD"]
 

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "hsflow_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i]),
     "hsflow_destroy": (_i, [_vp]),
     "hsflow_set_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_set_frames_u8_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_bgr8": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i]),
     "hsflow_set_frames_gray8_blur": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
@@ -57,6 +58,7 @@ PROTOTYPES = {
     "hsflow_solve_async": (_i, [_vp, _pp]),
     "hsflow_synchronize": (_i, [_vp]),
     "hsflow_get_flow": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_get_flow_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_derivatives": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
@@ -66,6 +68,17 @@ PROTOTYPES = {
     "hsflow_status_string": (ctypes.c_char_p, [_i]),
     "hsflow_version": (_i, []),
     "hsflow_device_count": (_i, [ctypes.POINTER(_i)]),
+    "hsflow_host_alloc": (_i, [ctypes.POINTER(_vp), _sz]),
+    "hsflow_host_free": (_i, [_vp]),
+    "hsflow_host_register": (_i, [_vp, _sz]),
+    "hsflow_host_unregister": (_i, [_vp]),
+    "hsflow_pipeline_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i]),
+    "hsflow_pipeline_destroy": (_i, [_vp]),
+    "hsflow_pipeline_submit": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
+    "hsflow_pipeline_wait": (_i, [_vp, ctypes.c_uint64]),
+    "hsflow_pipeline_drain": (_i, [_vp]),
+    "hsflow_pipeline_depth": (_i, [_vp]),
+    "hsflow_pipeline_last_error": (ctypes.c_char_p, [_vp]),
     "hsflow_calc_optical_flow_hs_8u32f": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i,
                                                ctypes.c_float, _i, _i, ctypes.c_double]),
 }

@@ -891,6 +891,36 @@ int hsflow_device_count(int *count)
     return HSFLOW_OK;
 }
 
+int hsflow_host_alloc(void **out, size_t bytes)
+{
+    if (!out || !bytes) return fail(nullptr, HSFLOW_E_ARG, "hsflow_host_alloc: null out or zero size");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(nullptr, HSFLOW_E_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return HSFLOW_OK;
+}
+
+int hsflow_host_free(void *p)
+{
+    if (!p) return HSFLOW_OK;
+    hipError_t e = hipHostFree(p);
+    return e == hipSuccess ? HSFLOW_OK : fail(nullptr, HSFLOW_E_ARG, std::string("hipHostFree: ") + hipGetErrorString(e));
+}
+
+int hsflow_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return fail(nullptr, HSFLOW_E_ARG, "hsflow_host_register: null pointer or zero size");
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    return e == hipSuccess ? HSFLOW_OK : fail(nullptr, HSFLOW_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e));
+}
+
+int hsflow_host_unregister(void *p)
+{
+    if (!p) return HSFLOW_OK;
+    hipError_t e = hipHostUnregister(p);
+    return e == hipSuccess ? HSFLOW_OK : fail(nullptr, HSFLOW_E_ARG, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+}
+
 int hsflow_version(void) { return HSFLOW_VERSION_MAJOR * 1000 + HSFLOW_VERSION_MINOR; }
 
 const char *hsflow_status_string(int s)
@@ -1002,6 +1032,28 @@ int hsflow_set_frames_u8(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps
     return HSFLOW_OK;
 }
 
+// One transfer of `rows` rows of `rowb` bytes between a pitched device plane and a host buffer on
+// ctx's stream.  Dense layouts on both sides take the 1-D path (a single SDMA copy).
+static hipError_t copy_rows_async(hsflow_ctx *c, void *dst, size_t dpitch, const void *src, size_t spitch, size_t rowb,
+                                  size_t rows, hipMemcpyKind kind)
+{
+    if (dpitch == rowb && spitch == rowb) return hipMemcpyAsync(dst, src, rowb * rows, kind, c->stream);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, rowb, rows, kind, c->stream);
+}
+
+int hsflow_set_frames_u8_async(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    HS_HIP(c, copy_rows_async(c, c->dA + pair * c->plane, c->P, prev, ps, c->W, c->H, hipMemcpyHostToDevice));
+    HS_HIP(c, copy_rows_async(c, c->dB + pair * c->plane, c->P, curr, cs, c->W, c->H, hipMemcpyHostToDevice));
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
 int hsflow_set_frames_u8_device(hsflow_ctx *c, int pair, const void *dprev, size_t ps, const void *dcurr, size_t cs)
 {
     int st = check_ctx(c, pair);
@@ -1102,6 +1154,18 @@ int hsflow_get_flow(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size
     HS_HIP(c, hipStreamSynchronize(c->stream));
     HS_HIP(c, hipMemcpy2D(u, us, c->dU[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
     HS_HIP(c, hipMemcpy2D(v, vs, c->dV[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
+    return HSFLOW_OK;
+}
+
+int hsflow_get_flow_async(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size_t vs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if (!u || !v) return fail(c, HSFLOW_E_ARG, "null flow pointer");
+    const size_t rowb = (size_t)c->W * 4;
+    if ((us & 3) || (vs & 3) || us < rowb || vs < rowb) return fail(c, HSFLOW_E_SIZE, "flow stride must be a multiple of 4 and >= 4*width");
+    HS_HIP(c, copy_rows_async(c, u, us, c->dU[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
+    HS_HIP(c, copy_rows_async(c, v, vs, c->dV[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
     return HSFLOW_OK;
 }
 

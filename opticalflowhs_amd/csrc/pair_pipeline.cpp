@@ -1,0 +1,132 @@
+// Pair pipeline: independent image pairs streamed through one GPU with the host<->device copies
+// of neighbouring pairs overlapped with the solve of the current one (include/hsflow.h).
+//
+// Reference behaviour replaced: HSOpticalFlowOpenCL::run() handles a pair as blocking write ->
+// derivatives -> iterations -> blocking read (HSOpticalFlowOpenCL.cpp:744-767); nothing overlaps.
+// Here `depth` single-pair contexts, each on a private stream, are used round-robin; the copy
+// engines and the compute queue work on three different pairs at once.  Built purely on the public
+// C ABI, so it is also the example of how a host drives several contexts from one thread.
+#include "../../include/hsflow.h"
+
+#include <new>
+#include <string>
+#include <vector>
+
+struct hsflow_pipeline {
+    struct Slot {
+        hsflow_ctx *ctx = nullptr;
+        bool busy = false;
+        uint64_t ticket = 0;
+    };
+    std::vector<Slot> slots;
+    uint64_t next = 0;
+    std::string err;
+};
+
+namespace {
+
+std::string g_pipeline_create_error;
+
+int pfail(hsflow_pipeline *pl, int code, const std::string &msg)
+{
+    if (pl) pl->err = msg; else g_pipeline_create_error = msg;
+    return code;
+}
+
+// Forwards a context error into the pipeline's error text.
+int ctx_fail(hsflow_pipeline *pl, hsflow_ctx *ctx, int code, const char *what)
+{
+    return pfail(pl, code, std::string(what) + ": " + hsflow_last_error(ctx));
+}
+
+int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
+{
+    if (!s.busy) return HSFLOW_OK;
+    s.busy = false; // also on failure: the job is over either way
+    const int st = hsflow_synchronize(s.ctx);
+    return st ? ctx_fail(pl, s.ctx, st, "hsflow_synchronize") : HSFLOW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int height, int depth)
+{
+    if (!out) return pfail(nullptr, HSFLOW_E_ARG, "out is null");
+    *out = nullptr;
+    if (depth < 1 || depth > 16) return pfail(nullptr, HSFLOW_E_ARG, "depth must be 1..16");
+    hsflow_pipeline *pl = new (std::nothrow) hsflow_pipeline();
+    if (!pl) return pfail(nullptr, HSFLOW_E_OOM, "host allocation failed");
+    pl->slots.resize((size_t)depth);
+    for (auto &s : pl->slots) {
+        const int st = hsflow_create(&s.ctx, device, width, height, 1, nullptr, /*own_stream*/ 1);
+        if (st) {
+            g_pipeline_create_error = std::string("hsflow_create: ") + hsflow_last_error(nullptr);
+            hsflow_pipeline_destroy(pl);
+            return st;
+        }
+    }
+    *out = pl;
+    return HSFLOW_OK;
+}
+
+int hsflow_pipeline_destroy(hsflow_pipeline *pl)
+{
+    if (!pl) return HSFLOW_OK;
+    for (auto &s : pl->slots) hsflow_destroy(s.ctx); // destroy synchronises the slot's stream
+    delete pl;
+    return HSFLOW_OK;
+}
+
+int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs,
+                           float *u, size_t us, float *v, size_t vs, const hsflow_params *params, uint64_t *ticket)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    if (!params) return pfail(pl, HSFLOW_E_ARG, "params is null");
+    if (!u || !v) return pfail(pl, HSFLOW_E_ARG, "null flow pointer");
+    hsflow_pipeline::Slot &s = pl->slots[pl->next % pl->slots.size()];
+    int st = finish_slot(pl, s); // the job that used this slot `depth` submissions ago
+    if (st) return st;
+    if ((st = hsflow_set_frames_u8_async(s.ctx, 0, prev, ps, curr, cs))) return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_async");
+    if ((st = hsflow_solve_async(s.ctx, params))) {
+        hsflow_synchronize(s.ctx); // the uploads were queued: do not leave them reading caller memory
+        return ctx_fail(pl, s.ctx, st, "hsflow_solve_async");
+    }
+    if ((st = hsflow_get_flow_async(s.ctx, 0, u, us, v, vs))) {
+        hsflow_synchronize(s.ctx);
+        return ctx_fail(pl, s.ctx, st, "hsflow_get_flow_async");
+    }
+    s.busy = true;
+    s.ticket = pl->next;
+    if (ticket) *ticket = pl->next;
+    pl->next++;
+    return HSFLOW_OK;
+}
+
+int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    if (ticket >= pl->next) return pfail(pl, HSFLOW_E_ARG, "ticket was never issued");
+    hsflow_pipeline::Slot &s = pl->slots[ticket % pl->slots.size()];
+    // a later job on the same slot means this one was already waited for inside submit()
+    if (!s.busy || s.ticket != ticket) return HSFLOW_OK;
+    return finish_slot(pl, s);
+}
+
+int hsflow_pipeline_drain(hsflow_pipeline *pl)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    int first = HSFLOW_OK;
+    for (auto &s : pl->slots) {
+        const int st = finish_slot(pl, s);
+        if (st && !first) first = st;
+    }
+    return first;
+}
+
+int hsflow_pipeline_depth(hsflow_pipeline *pl) { return pl ? (int)pl->slots.size() : 0; }
+
+const char *hsflow_pipeline_last_error(hsflow_pipeline *pl) { return pl ? pl->err.c_str() : g_pipeline_create_error.c_str(); }
+
+} // extern "C"

@@ -1,0 +1,94 @@
+"""Independent pairs streamed through one GPU: host frames in, host flow out (BASELINE config C4).
+
+Mirror of `hsflow_pipeline_*` (include/hsflow.h).  The reference handles a pair as blocking write ->
+derivatives -> iterations -> blocking read (HSOpticalFlowOpenCL.cpp:744-767); the pipeline keeps
+`depth` pairs in flight on separate streams so that the PCIe copies of the neighbouring pairs run
+beside the solve of the current one.  Host buffers should be page-locked (`pinned_empty`).
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import HsflowError, TERM_ITER
+from .solver import make_params
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory (hsflow_host_alloc); freed with the array."""
+    lib = _lib.load()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = ctypes.c_void_p()
+    st = lib.hsflow_host_alloc(ctypes.byref(p), max(n, 1))
+    if st:
+        raise HsflowError(st, (lib.hsflow_last_error(None) or b"").decode())
+    buf = (ctypes.c_ubyte * max(n, 1)).from_address(p.value)
+    weakref.finalize(buf, lib.hsflow_host_free, ctypes.c_void_p(p.value))  # runs when the last view is gone
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+class PairPipeline(object):
+    """`depth` single-pair contexts used round-robin; ITER-only termination."""
+
+    def __init__(self, width, height, depth=4, device=0):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.width, self.height = int(width), int(height)
+        st = self._lib.hsflow_pipeline_create(ctypes.byref(self._h), int(device), self.width, self.height, int(depth))
+        if st:
+            self._h = None
+            raise HsflowError(st, (self._lib.hsflow_pipeline_last_error(None) or b"").decode())
+        self.depth = self._lib.hsflow_pipeline_depth(self._h)
+        self._held = {}  # ticket -> arrays kept alive while the device may touch them
+
+    def _check(self, st):
+        if st:
+            raise HsflowError(st, (self._lib.hsflow_pipeline_last_error(self._h) or b"").decode())
+
+    def submit(self, prev, curr, u_out, v_out, params=None, **kw):
+        """Enqueues upload -> solve -> download of one pair; returns its ticket.  The four arrays
+        belong to the pipeline until `wait(ticket)` (or `drain()`) returned."""
+        for a, dt in ((prev, np.uint8), (curr, np.uint8), (u_out, np.float32), (v_out, np.float32)):
+            if not isinstance(a, np.ndarray) or a.dtype != dt or a.shape != (self.height, self.width) or a.strides[1] != a.itemsize:
+                raise ValueError("pipeline buffers must be (height, width) arrays: u8 frames, fp32 flow, unit column stride")
+        if not (u_out.flags.writeable and v_out.flags.writeable):
+            raise ValueError("flow outputs must be writeable")
+        if params is None:
+            kw.setdefault("term_type", TERM_ITER)
+            params = make_params(**kw)
+        t = ctypes.c_uint64()
+        self._check(self._lib.hsflow_pipeline_submit(
+            self._h, ctypes.c_void_p(prev.ctypes.data), prev.strides[0], ctypes.c_void_p(curr.ctypes.data), curr.strides[0],
+            ctypes.c_void_p(u_out.ctypes.data), u_out.strides[0], ctypes.c_void_p(v_out.ctypes.data), v_out.strides[0],
+            ctypes.byref(params), ctypes.byref(t)))
+        self._held.pop(t.value - self.depth, None)  # that slot was waited for inside submit
+        self._held[t.value] = (prev, curr, u_out, v_out)
+        return t.value
+
+    def wait(self, ticket):
+        self._check(self._lib.hsflow_pipeline_wait(self._h, int(ticket)))
+        self._held.pop(int(ticket), None)
+
+    def drain(self):
+        self._check(self._lib.hsflow_pipeline_drain(self._h))
+        self._held.clear()
+
+    def close(self):
+        if self._h is not None:
+            self._lib.hsflow_pipeline_destroy(self._h)
+            self._h = None
+            self._held.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -38,6 +38,31 @@ def _is_device_tensor(x):
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
+def make_params(lam=1.0, max_iter=100, epsilon=1e-6, term_type=TERM_ITER | TERM_EPS,
+                use_previous=False, mode=MODE_CV, alpha=1.0, kernel=KERNEL_AUTO, fuse_steps=0,
+                tile_w=0, tile_h=0, threads=0, strip_rows=0, reuse_derivatives=False, use_graph=False,
+                profile=False):
+    p = HsflowParams()
+    _lib.load().hsflow_default_params(ctypes.byref(p))
+    p.mode = mode
+    p.lambda_ = lam
+    p.alpha = alpha
+    p.term_type = term_type
+    p.max_iter = max_iter
+    p.epsilon = epsilon
+    p.use_previous = 1 if use_previous else 0
+    p.kernel = kernel
+    p.fuse_steps = fuse_steps
+    p.tile_w = tile_w
+    p.tile_h = tile_h
+    p.threads = threads
+    p.strip_rows = strip_rows
+    p.reuse_derivatives = 1 if reuse_derivatives else 0
+    p.use_graph = 1 if use_graph else 0
+    p.profile = 1 if profile else 0
+    return p
+
+
 class HSFlow(object):
     """A solver context holding `n_pairs` image pairs of one size resident on one GPU."""
 
@@ -123,29 +148,9 @@ class HSFlow(object):
         self._check(self._lib.hsflow_push_frame_u8(self._h, pair, _ptr(nxt), nxt.strides[0]))
 
     # -- solve ---------------------------------------------------------------------------
-    def make_params(self, lam=1.0, max_iter=100, epsilon=1e-6, term_type=TERM_ITER | TERM_EPS,
-                    use_previous=False, mode=MODE_CV, alpha=1.0, kernel=KERNEL_AUTO, fuse_steps=0,
-                    tile_w=0, tile_h=0, threads=0, strip_rows=0, reuse_derivatives=False, use_graph=False,
-                    profile=False):
-        p = HsflowParams()
-        self._lib.hsflow_default_params(ctypes.byref(p))
-        p.mode = mode
-        p.lambda_ = lam
-        p.alpha = alpha
-        p.term_type = term_type
-        p.max_iter = max_iter
-        p.epsilon = epsilon
-        p.use_previous = 1 if use_previous else 0
-        p.kernel = kernel
-        p.fuse_steps = fuse_steps
-        p.tile_w = tile_w
-        p.tile_h = tile_h
-        p.threads = threads
-        p.strip_rows = strip_rows
-        p.reuse_derivatives = 1 if reuse_derivatives else 0
-        p.use_graph = 1 if use_graph else 0
-        p.profile = 1 if profile else 0
-        return p
+    def make_params(self, **kw):
+        """hsflow_params with the defaults of hsflow_default_params; see `make_params` (module)."""
+        return make_params(**kw)
 
     def solve(self, params=None, **kw):
         p = params if params is not None else self.make_params(**kw)

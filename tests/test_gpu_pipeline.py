@@ -1,0 +1,102 @@
+"""Pair pipeline (hsflow_pipeline_*): host buffers in/out with overlapped copies must give exactly
+what the resident-context path gives, pair by pair, whatever the depth or the wait order."""
+import numpy as np
+import pytest
+
+from opticalflowhs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ITER = 1
+RMS_TOL = 1e-4  # north_star tolerance on u and v against the oracle
+
+
+def _pairs(n, W, H):
+    out = []
+    for i in range(n):
+        if i % 2:
+            out.append(synth.random_pair(W, H, seed=300 + i))
+        else:
+            out.append(synth.translating_pair(W, H, seed=300 + i, dx=0.5 + 0.1 * i, dy=-0.25))
+    return out
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 5])
+def test_pipeline_matches_resident_context_and_oracle(hs, oracle, gpu_ok, depth):
+    W, H, it, n = 200, 120, 30, 7
+    pairs = _pairs(n, W, H)
+    ref = []
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        for A, B in pairs:
+            ctx.set_frames(A, B)
+            ctx.solve(lam=0.5, max_iter=it, term_type=ITER)
+            ref.append(ctx.flow())
+    with hs.PairPipeline(W, H, depth=depth) as pl:
+        assert pl.depth == depth
+        bufs, tickets = [], []
+        for A, B in pairs:
+            a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)
+            a[...] = A
+            b[...] = B
+            u, v = hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)
+            u.fill(np.nan)
+            v.fill(np.nan)
+            tickets.append(pl.submit(a, b, u, v, lam=0.5, max_iter=it))
+            bufs.append((u, v))
+        assert tickets == list(range(n))
+        for t in [n - 1, 0] + list(range(1, n - 1)):  # out of order, some already finished inside submit
+            pl.wait(t)
+            u, v = bufs[t]
+            assert np.array_equal(u, ref[t][0]) and np.array_equal(v, ref[t][1]), t
+        pl.drain()
+    for (A, B), (u, v) in zip(pairs[:3], bufs[:3]):
+        uo, vo = oracle.calc_optical_flow_hs(A, B, 0.5, it, term_type=ITER)
+        assert np.sqrt(np.mean((u.astype(np.float64) - uo) ** 2)) <= RMS_TOL
+        assert np.sqrt(np.mean((v.astype(np.float64) - vo) ** 2)) <= RMS_TOL
+
+
+def test_pipeline_pageable_strided_buffers_and_reuse(hs, gpu_ok):
+    W, H, it = 130, 70, 12
+    pairs = _pairs(4, W, H)
+    with hs.HSFlow(W, H, own_stream=True) as ctx, hs.PairPipeline(W, H, depth=2) as pl:
+        frames = np.zeros((2, H, W + 9), np.uint8)       # row stride > width
+        flow = np.full((2, H, W + 5), np.nan, np.float32)
+        for rnd in range(2):                              # the same buffers go round twice
+            for A, B in pairs[2 * rnd:2 * rnd + 2]:
+                frames[0, :, :W], frames[1, :, :W] = A, B
+                t = pl.submit(frames[0, :, :W], frames[1, :, :W], flow[0, :, :W], flow[1, :, :W], lam=2.0, max_iter=it,
+                              kernel=hs.KERNEL_FUSED)
+                pl.wait(t)
+                ctx.set_frames(A, B)
+                ctx.solve(lam=2.0, max_iter=it, term_type=ITER)
+                u, v = ctx.flow()
+                assert np.array_equal(flow[0, :, :W], u) and np.array_equal(flow[1, :, :W], v)
+                assert np.isnan(flow[:, :, W:]).all()      # padding columns untouched
+
+
+def test_pipeline_errors(hs, gpu_ok):
+    W, H = 64, 32
+    with pytest.raises(hs.HsflowError) as e:
+        hs.PairPipeline(W, H, depth=0)
+    assert e.value.status == hs._lib.E_ARG
+    with pytest.raises(hs.HsflowError) as e:
+        hs.PairPipeline(0, H, depth=2)
+    assert e.value.status == hs._lib.E_SIZE
+    A, B = synth.random_pair(W, H, seed=5)
+    u, v = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+    with hs.PairPipeline(W, H, depth=2) as pl:
+        with pytest.raises(hs.HsflowError) as e:      # EPS termination needs the host in the loop
+            pl.submit(A, B, u, v, lam=1.0, max_iter=5, term_type=hs.TERM_ITER | hs.TERM_EPS)
+        assert e.value.status == hs._lib.E_ARG and "ITER-only" in str(e.value)
+        with pytest.raises(hs.HsflowError) as e:
+            pl.wait(0)                                # nothing was issued
+        assert e.value.status == hs._lib.E_ARG
+        with pytest.raises(ValueError):
+            pl.submit(A[:, :-1], B, u, v, max_iter=5)
+        with pytest.raises(ValueError):
+            pl.submit(A, B, u.astype(np.float64), v, max_iter=5)
+        t = pl.submit(A, B, u, v, lam=1.0, max_iter=5)  # still usable after the failures
+        assert t == 0
+        pl.wait(t)
+        pl.wait(t)                                    # idempotent
+        assert np.isfinite(u).all() and np.abs(u).max() > 0
