@@ -61,6 +61,10 @@ extern "C" {
 #define HSFLOW_MODE_CLASSIC 1 /* Kernels.cl semantics: 2x2x2 cube derivatives, 1/6-1/12 mean,
                                  alpha^2, with the v update restored    */
 
+#define HSFLOW_MODE_CLASSIC_AS_SHIPPED 2 /* Kernels.cl exactly as shipped: u_v_updateKernel writes u only
+                                 (Kernels.cl:86), v stays at its starting value.  Reproduces the
+                                 pictures the reference's OpenCL route wrote; for verification      */
+
 /* Jacobi kernel selection */
 #define HSFLOW_KERNEL_AUTO 0
 #define HSFLOW_KERNEL_SIMPLE 1 /* one iteration per launch, straight from HBM/L2             */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HSFLOW_LIB_PATH") or os.path.join(HERE, "libhsflow.so
 # status codes / enums of include/hsflow.h
 OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
 TERM_ITER, TERM_EPS = 1, 2
-MODE_CV, MODE_CLASSIC = 0, 1
+MODE_CV, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED = 0, 1, 2
 KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP, KERNEL_FOLD = 0, 1, 2, 3, 4
 
 

@@ -76,9 +76,10 @@ int HSOpticalFlowOpenCL::solvePair(const pnm::Image &a, const pnm::Image &b, boo
     hsflow_default_params(&p);
     // the "-cl" route keeps the reference kernels' own discretisation (Kernels.cl: cube derivatives,
     // 1/6-1/12 mean, alpha^2) -- with the v update the reference forgot; HSFLOW_CL_AS_CV=1 switches
-    // to the OpenCV discretisation with the equivalent regulariser lambda = 1/alpha^2
+    // to the OpenCV discretisation with the equivalent regulariser lambda = 1/alpha^2,
+    // HSFLOW_CL_AS_SHIPPED=1 to Kernels.cl as shipped (v never written: the reference's pictures)
     if (getenv("HSFLOW_CL_AS_CV")) p.lambda = 1.0f / (alpha * alpha);
-    else { p.mode = HSFLOW_MODE_CLASSIC; p.alpha = alpha; }
+    else { p.mode = getenv("HSFLOW_CL_AS_SHIPPED") ? HSFLOW_MODE_CLASSIC_AS_SHIPPED : HSFLOW_MODE_CLASSIC; p.alpha = alpha; }
     p.term_type = HSFLOW_TERM_ITER;        // the reference loop runs a fixed count (:750-751)
     p.max_iter = iterations;
     const double t0 = now_ms();

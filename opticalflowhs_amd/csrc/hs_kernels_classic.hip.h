@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void k_deriv_classic(const uint8_t *__restrict
     *(float4 *)(Et + o) = make_float4(et[0], et[1], et[2], et[3]);
 }
 
-template <bool ZERO>
+// WRITE_V = false is Kernels.cl exactly as shipped: u_v_updateKernel writes u only (Kernels.cl:86), so
+// v keeps its starting value for ever (the ping-pong buffers just carry it along).  The product default
+// restores the v update; the as-shipped form exists so that the HIP path can be held against the
+// pictures the reference's OpenCL route wrote (tests/refpics.py).
+template <bool ZERO, bool WRITE_V>
 __global__ __launch_bounds__(256) void k_jacobi_classic(const float *__restrict__ Ex, const float *__restrict__ Ey,
                                                         const float *__restrict__ Et, const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in, float *__restrict__ u_out,
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(256) void k_jacobi_classic(const float *__restrict_
         float t = ex[k] * ua + ey[k] * va + et[k];
         t /= alpha2 + ex[k] * ex[k] + ey[k] * ey[k];
         nu[k] = ua - ex[k] * t;
-        nv[k] = va - ey[k] * t; // restored: the reference kernel forgot this line (Kernels.cl:84-86)
+        nv[k] = WRITE_V ? va - ey[k] * t // restored: the reference kernel forgot this line (Kernels.cl:84-86)
+                        : wv[1][c];
     }
     *(float4 *)(u_out + o) = make_float4(nu[0], nu[1], nu[2], nu[3]);
     *(float4 *)(v_out + o) = make_float4(nv[0], nv[1], nv[2], nv[3]);

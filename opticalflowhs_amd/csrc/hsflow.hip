@@ -574,17 +574,16 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     c->coef_valid = true;
     c->coef_mode = HSFLOW_MODE_CLASSIC;
     const float a2 = p.alpha * p.alpha; // Kernels.cl:85
+    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
     int zero = p.use_previous ? 0 : 1;
     if (zero) c->cur = 0;
     for (int it = 0; it < p.max_iter; it++) {
         const int a = c->cur, b = a ^ 1;
         prof.begin(1);
-        if (zero)
-            hipLaunchKernelGGL(hsk::k_jacobi_classic<true>, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2],
-                               c->dU[a], c->dV[a], c->dU[b], c->dV[b], c->W, c->H, c->P, c->plane, a2);
-        else
-            hipLaunchKernelGGL(hsk::k_jacobi_classic<false>, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2],
-                               c->dU[a], c->dV[a], c->dU[b], c->dV[b], c->W, c->H, c->P, c->plane, a2);
+        auto kern = zero ? (write_v ? hsk::k_jacobi_classic<true, true> : hsk::k_jacobi_classic<true, false>)
+                         : (write_v ? hsk::k_jacobi_classic<false, true> : hsk::k_jacobi_classic<false, false>);
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2], c->dU[a], c->dV[a], c->dU[b], c->dV[b],
+                           c->W, c->H, c->P, c->plane, a2);
         HS_HIP(c, hipGetLastError());
         prof.end();
         c->cur = b;
@@ -609,7 +608,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
     const hsflow_params &p = *pp;
     if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
-    if (p.mode == HSFLOW_MODE_CLASSIC) return solve_classic(c, p, async);
+    if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) return solve_classic(c, p, async);
     if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
     const bool use_iter = (p.term_type & HSFLOW_TERM_ITER) != 0, use_eps = (p.term_type & HSFLOW_TERM_EPS) != 0;
     if (!use_iter && !use_eps) return fail(c, HSFLOW_E_ARG, "term_type must include ITER and/or EPS");

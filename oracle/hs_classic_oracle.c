@@ -14,9 +14,12 @@
  * planes here are single-channel fp32.  Frames enter as u8 gray, converted with (float) exactly as
  * readInputImage does (HSOpticalFlowOpenCL.cpp:15-20).
  *
- * PARITY UNPINNED: the reference records no numeric output of this path (only arrow pictures),
- * and an OpenCL compiler may contract a*b+c (FP_CONTRACT defaults ON), so this oracle states the
- * un-contracted fp32 evaluation in source order; tests compare with a tolerance.
+ * PINNED BY THE REFERENCE'S RECORDED OUTPUTS, at drawing resolution: the two pictures its OpenCL
+ * route wrote (OpticalFlowHS/city_cl_out.jpg, bunny_cl_out.jpg; dot + line where |u| > 0.5) are
+ * reproduced pixel for pixel by the as-shipped form below (updateV = 0, alpha 15, 10 sweeps; see
+ * tests/refpics.py).  No numeric output is recorded, and an OpenCL compiler may contract a*b+c
+ * (FP_CONTRACT defaults ON), so below the drawing's resolution this oracle states the un-contracted
+ * fp32 evaluation in source order: "parity unpinned" at the level of the last bits.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -59,9 +62,14 @@ int hs_oracle_classic_derivatives(const uint8_t *imgA, const uint8_t *imgB, int 
     return 0;
 }
 
-/* Full solve, fixed iteration count (the reference has no other stop rule, :750-751). */
-int hs_oracle_classic(const uint8_t *imgA, const uint8_t *imgB, int imgStep, int W, int H,
-                      int usePrevious, float *u, float *v, int velStep, float alpha, int iterations)
+/* Full solve, fixed iteration count (the reference has no other stop rule, :750-751).
+ * updateV = 1: the intended scheme.  updateV = 0: Kernels.cl exactly as shipped -- line 86 writes
+ * u only, so v keeps its initial value (zero, HSOpticalFlowOpenCL.cpp:332) for ever; this form
+ * exists to hold the restatement against the pictures the reference's OpenCL route wrote
+ * (OpticalFlowHS/city_cl_out.jpg, bunny_cl_out.jpg; tests/test_reference_pictures.py). */
+int hs_oracle_classic_ex(const uint8_t *imgA, const uint8_t *imgB, int imgStep, int W, int H,
+                         int usePrevious, float *u, float *v, int velStep, float alpha, int iterations,
+                         int updateV)
 {
     if (!imgA || !imgB || !u || !v) return -2;
     if (W <= 0 || H <= 0 || W > imgStep || (velStep & 3) || W * 4 > velStep || iterations < 0)
@@ -107,7 +115,7 @@ int hs_oracle_classic(const uint8_t *imgA, const uint8_t *imgB, int imgStep, int
             float t = Ex[p] * ua[p] + Ey[p] * va[p] + Et[p];
             t /= a2 + Ex[p] * Ex[p] + Ey[p] * Ey[p];
             uu[p] = ua[p] - Ex[p] * t;
-            vv[p] = va[p] - Ey[p] * t;
+            if (updateV) vv[p] = va[p] - Ey[p] * t;
         }
     }
     for (int y = 0; y < H; y++) {
@@ -116,4 +124,10 @@ int hs_oracle_classic(const uint8_t *imgA, const uint8_t *imgB, int imgStep, int
     }
     free(mem);
     return 0;
+}
+
+int hs_oracle_classic(const uint8_t *imgA, const uint8_t *imgB, int imgStep, int W, int H,
+                      int usePrevious, float *u, float *v, int velStep, float alpha, int iterations)
+{
+    return hs_oracle_classic_ex(imgA, imgB, imgStep, W, H, usePrevious, u, v, velStep, alpha, iterations, 1);
 }

@@ -18,9 +18,16 @@
  *                     eps       VA 0x1012ed2f-0x1012eda5  Eps = max |old-new| (fp32)
  *                     stop      VA 0x1012f10b-0x1012f14a
  *
- * PARITY UNPINNED: the reference holds no test, golden vector or recorded output for this path
- *  and the DLL cannot be run here, so this oracle is pinned only by
- * analytic known-answer tests and by an independent NumPy restatement (oracle/hs_numpy.py).
+ * PINNED BY THE REFERENCE'S RECORDED OUTPUTS, at drawing resolution: the reference holds no test
+ * or numeric vector for this path and the DLL cannot be run here, but it does hold the two
+ * pictures its CPU route wrote with the real cvCalcOpticalFlowHS (OpticalFlowHS/city_cv_out.jpg,
+ * bunny_cv_out.jpg: a dot + line per 4x4 grid point where |u| or |v| > 1).  Re-drawing THIS
+ * oracle's flow (lambda 0.1, 10 sweeps, after gray + 3x3 blur) and saving it as JPEG decodes to
+ * those pictures with no pixel different: 24 360 drawn / not-drawn decisions and every line end
+ * point trunc(x+u/2), trunc(y+v/2) agree, the closest sampled values lying 1e-4..1e-3 from a
+ * boundary (tests/refpics.py, tests/test_reference_pictures.py).  Nothing pins the last fp32 bits:
+ * below ~1e-3 the oracle rests on the disassembly read, analytic known-answer tests and an
+ * independent NumPy restatement (oracle/hs_numpy.py); "parity unpinned" at that level.
  *
  * x87 note: the DLL evaluates expressions on the x87 stack under the Win32 default 53-bit
  * precision control and rounds to fp32 at every store to a float.  `double` temporaries with

@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE ONLY.  Written separately from oracle/hs_cv_oracle.c (whole-array operations,
 np.pad for the replicate border) so that the two restatements cross-check each other; both follow
 SURVEY.md section 8c, i.e. cvCalcOpticalFlowHS as called at OpticalFlowHS/OpticalFlowOpenCV.cpp:29
-(declaration OpenCV2.1/include/cv.h:481-483).  PARITY UNPINNED -- see hs_cv_oracle.c.
+(declaration OpenCV2.1/include/cv.h:481-483).  Parity status: see the header of hs_cv_oracle.c (pinned by the reference's output pictures at
+drawing resolution, unpinned at the last fp32 bits).
 """
 import numpy as np
 

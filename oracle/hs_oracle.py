@@ -54,6 +54,8 @@ def lib():
                                         ctypes.c_int, f32p, f32p, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_int]
         L.hs_oracle_classic.restype = ctypes.c_int
+        L.hs_oracle_classic_ex.argtypes = L.hs_oracle_classic.argtypes + [ctypes.c_int]
+        L.hs_oracle_classic_ex.restype = ctypes.c_int
         L.hs_oracle_classic_derivatives.argtypes = L.hs_oracle_cv_derivatives.argtypes
         L.hs_oracle_classic_derivatives.restype = ctypes.c_int
         L.hs_oracle_bgr2gray_u8.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p,
@@ -129,7 +131,8 @@ def derivatives(prev, curr):
     return Ix, Iy, It
 
 
-def classic_flow(prev, curr, alpha, iterations, use_previous=False, u0=None, v0=None):
+def classic_flow(prev, curr, alpha, iterations, use_previous=False, u0=None, v0=None, update_v=True):
+    """update_v=False: Kernels.cl as shipped (v never written, Kernels.cl:84-86)."""
     prev, curr = _check_frames(prev, curr)
     H, W = prev.shape
     if use_previous:
@@ -138,8 +141,8 @@ def classic_flow(prev, curr, alpha, iterations, use_previous=False, u0=None, v0=
     else:
         u = np.empty((H, W), np.float32)
         v = np.empty((H, W), np.float32)
-    st = lib().hs_oracle_classic(_u8(prev), _u8(curr), W, W, H, int(bool(use_previous)), _f32(u),
-                                 _f32(v), W * 4, float(alpha), int(iterations))
+    st = lib().hs_oracle_classic_ex(_u8(prev), _u8(curr), W, W, H, int(bool(use_previous)), _f32(u),
+                                    _f32(v), W * 4, float(alpha), int(iterations), int(bool(update_v)))
     if st != 0:
         raise RuntimeError("oracle status %d" % st)
     return u, v

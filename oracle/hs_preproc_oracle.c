@@ -11,7 +11,8 @@
  *   gray = (1868*B + 9617*G + 4899*R + 8192) >> 14      (fixed point, 14 fractional bits:
  *          0.114, 0.587, 0.299 rounded to 1/16384)
  *   blur = round_half_even( sum_3x3 / 9 ), replicate border (cvSmooth's border mode)
- * PARITY UNPINNED: the reference holds no vector for either; parity is defined on identical u8
+ * Pinned only through the pictures of the CPU route (tests/refpics.py: without the blur they are not
+ * reproduced); the reference holds no vector for either; parity is defined on identical u8
  * inputs to the solver, so these only matter for end-to-end runs from colour images.
  */
 #include <stdint.h>

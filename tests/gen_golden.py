@@ -10,9 +10,19 @@ The bunny frames come from the reference's data files OpticalFlowHS/bunny_1.jpg 
 (424x240), decoded with PIL in this container, converted with the BGR2GRAY fixed-point formula
 (oracle/hs_preproc_oracle.c); JPEG decoding is not bit-identical to OpenCV 2.1's libjpeg, which
 is fine because parity is defined on identical u8 inputs to both solvers.
+
+The only outputs of the path that the reference holds are pictures: its CPU route
+(OpticalFlowOpenCV.cpp:31-47) wrote OpticalFlowHS/city_cv_out.jpg and bunny_cv_out.jpg, its OpenCL
+route (HSOpticalFlowOpenCL.cpp:755-772) city_cl_out.jpg and bunny_cl_out.jpg -- a blue dot + red
+line at every 4th pixel in x and y where the flow exceeds a threshold.  Those four data files are
+copied to tests/golden/ref_*.jpg (31-44 KB each); tests/refpics.py re-draws the oracle's / the HIP
+path's flow by the same rule and compares the pictures (tests/test_reference_pictures.py,
+tests/test_gpu_frontend.py).  `reference_picture_grid` additionally reduces the two CPU-route
+pictures to the mean blue / red level around every grid point, for a check that needs no JPEG codec.
 """
 import hashlib
 import os
+import shutil
 import sys
 
 import numpy as np
@@ -31,6 +41,17 @@ def write_pgm(path, img):
     with open(path, "wb") as f:
         f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
         f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
+
+
+def reference_picture_grid(rgb, step=4):
+    """3x3 mean of the blue and red channel around every grid point (y, x multiples of `step`)."""
+    H, W = rgb.shape[:2]
+    out = []
+    for ch in (2, 0):
+        pad = np.pad(rgb[:, :, ch].astype(np.int32), 1, mode="edge")
+        acc = sum(pad[1 + dy:1 + dy + H, 1 + dx:1 + dx + W][::step, ::step] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+        out.append(((acc + 4) // 9).astype(np.uint8))
+    return out
 
 
 def both(A, B, lam, it, tt=ITER, eps=1e-6):
@@ -78,6 +99,18 @@ def main():
             frames.append(hs_oracle.box_blur3(gray))
         u, v, n, e = both(frames[0], frames[1], 1.0, 50, ITER | EPS, 1e-6)
         np.savez_compressed(os.path.join(OUT, "bunny_flow_l1_i50.npz"), u=u, v=v, iters=np.int32(n))
+        # the second pair the reference ships, and what its CPU route drew for both pairs
+        grids = {}
+        for name in ("city_1.jpg", "city_2.jpg"):
+            rgb = np.asarray(Image.open(os.path.join(REF, name)).convert("RGB"))
+            write_pgm(os.path.join(OUT, name.replace(".jpg", "_gray.pgm")), hs_oracle.bgr2gray(rgb[:, :, ::-1]))
+        for name in ("city", "bunny"):
+            # the pictures themselves (data files) for the full-resolution comparison
+            for route in ("cv", "cl"):
+                shutil.copyfile(os.path.join(REF, "%s_%s_out.jpg" % (name, route)), os.path.join(OUT, "ref_%s_%s_out.jpg" % (name, route)))
+            rgb = np.asarray(Image.open(os.path.join(REF, name + "_cv_out.jpg")).convert("RGB"))
+            grids[name + "_blue"], grids[name + "_red"] = reference_picture_grid(rgb)
+        np.savez_compressed(os.path.join(OUT, "ref_cv_out_grids.npz"), **grids)
     else:
         print("reference not present: bunny fixtures left as they are")
 

@@ -158,3 +158,69 @@ def test_cpp_dropin_cli(hs, oracle, gpu_ok, tmp_path):
     assert "Wrong argument list" in r.stdout
     r = subprocess.run([cli, "-cv", "-hd", str(tmp_path / "missing.pgm"), p2, out_cv, "0.1", "5"], env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode == 255 and "Input image error" in r.stdout
+
+
+def _cli(args, tmp_path, extra_env=None):
+    cli = os.path.join(ROOT, "opticalflowhs_amd", "hsflow_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "opticalflowhs_amd", "csrc"), "-s", "host"])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "opticalflowhs_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.update(extra_env or {})
+    r = subprocess.run([cli] + args, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+@pytest.mark.parametrize("name", ["city", "bunny"])
+def test_hip_path_reproduces_the_cpu_route_pictures(hs, oracle, gpu_ok, tmp_path, name):
+    """The pictures the reference's CPU route wrote (cvCalcOpticalFlowHS inside; tests/refpics.py) vs
+    the HIP path: through the Python mirror (blur + ITER|EPS solve on the device) and through the C++
+    drop-in's `-cv` command line.  Saved as JPEG, both drawings must BE the reference's picture."""
+    pytest.importorskip("PIL")
+    import refpics
+    A0, B0 = refpics.gray_pair(name)
+    H, W = A0.shape
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        ctx.set_frames_gray_blur(A0, B0)
+        info = ctx.solve(lam=refpics.LAMBDA, max_iter=refpics.ITERATIONS, epsilon=refpics.EPSILON, term_type=ITER | EPS)
+        u, v = ctx.flow()
+    assert info["iterations_done"] == refpics.ITERATIONS
+    wrong, quality = refpics.picture_difference(refpics.render(u, v), name)
+    assert wrong == 0, (wrong, quality)
+    uo, vo = oracle.calc_optical_flow_hs(oracle.box_blur3(A0), oracle.box_blur3(B0), refpics.LAMBDA, refpics.ITERATIONS,
+                                         refpics.EPSILON, ITER | EPS)
+    assert rms(u, uo) <= 1e-4 and rms(v, vo) <= 1e-4
+    out = str(tmp_path / "out.ppm")
+    _cli(["-cv", "-hd", os.path.join(GOLDEN, name + "_1_gray.pgm"), os.path.join(GOLDEN, name + "_2_gray.pgm"), out, ".1", "10"], tmp_path)
+    drawn = read_ppm(out)
+    assert np.array_equal(drawn, refpics.render(u, v))          # the C++ drawing = the rule as restated in refpics
+    assert refpics.picture_difference(drawn, name)[0] == 0
+
+
+@pytest.mark.parametrize("name", ["city", "bunny"])
+def test_hip_path_reproduces_the_opencl_route_pictures(hs, oracle, gpu_ok, tmp_path, name):
+    """The pictures the reference's OpenCL route wrote (Kernels.cl as shipped: v never written) vs the
+    HIP classic kernels in MODE_CLASSIC_AS_SHIPPED, via the Python mirror and via `-cl` of the drop-in."""
+    pytest.importorskip("PIL")
+    import refpics
+    A, B = refpics.gray_pair(name)
+    H, W = A.shape
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        ctx.solve(mode=hs.MODE_CLASSIC_AS_SHIPPED, alpha=refpics.ALPHA, max_iter=refpics.ITERATIONS, term_type=ITER)
+        u, v = ctx.flow()
+        uo, vo = oracle.classic_flow(A, B, refpics.ALPHA, refpics.ITERATIONS, update_v=False)
+        assert np.array_equal(u, uo) and not v.any()
+        ctx.solve(mode=hs.MODE_CLASSIC, alpha=refpics.ALPHA, max_iter=refpics.ITERATIONS, term_type=ITER)  # intended scheme
+        u2, v2 = ctx.flow()
+        uo2, vo2 = oracle.classic_flow(A, B, refpics.ALPHA, refpics.ITERATIONS)
+        assert np.array_equal(u2, uo2) and np.array_equal(v2, vo2) and v2.any()
+    assert refpics.picture_difference(refpics.render(u, v, "cl"), name, "cl")[0] == 0
+    out = str(tmp_path / "out.ppm")
+    args = ["-cl", "-hd", os.path.join(GOLDEN, name + "_1_gray.pgm"), os.path.join(GOLDEN, name + "_2_gray.pgm"), out, "15", "10", "1", "GPU"]
+    _cli(args, tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
+    drawn = read_ppm(out)
+    assert np.array_equal(drawn, refpics.render(u, v, "cl"))
+    assert refpics.picture_difference(drawn, name, "cl")[0] == 0
+    _cli(args, tmp_path)                                        # default: v update restored -> a different picture
+    assert refpics.picture_difference(read_ppm(out), name, "cl")[0] > 200

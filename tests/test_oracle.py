@@ -2,7 +2,8 @@
 
 The reference has no tests or golden vectors for this path, so the oracle is pinned by analytic
 known-answer tests, by an independent NumPy restatement and by committed fixtures
-(tests/gen_golden.py).  PARITY UNPINNED against the real cv210.dll: it cannot be run here.
+(tests/gen_golden.py).  The real cv210.dll cannot be run here; what pins the oracle to it are the reference's own output
+pictures (tests/test_reference_pictures.py).
 """
 import hashlib
 import os

@@ -1,0 +1,73 @@
+"""Oracle vs the only outputs of the path that the reference holds: the four pictures its two routes
+wrote (see tests/refpics.py).  CPU-only; the GPU twin is in tests/test_gpu_frontend.py."""
+import numpy as np
+import pytest
+
+import refpics
+
+ITER_EPS = 3
+NAMES = ["city", "bunny"]
+
+
+def cv_flow(oracle, A, B, lam=refpics.LAMBDA, it=refpics.ITERATIONS):
+    return oracle.calc_optical_flow_hs(A, B, lam, it, epsilon=refpics.EPSILON, term_type=ITER_EPS)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_the_cpu_route_pictures(oracle, name):
+    """cvCalcOpticalFlowHS as run by the reference's authors vs oracle/hs_cv_oracle.c."""
+    pytest.importorskip("PIL")
+    A0, B0 = refpics.gray_pair(name)
+    A, B = oracle.box_blur3(A0), oracle.box_blur3(B0)
+    u, v = cv_flow(oracle, A, B)
+    wrong, quality = refpics.picture_difference(refpics.render(u, v), name)
+    assert wrong == 0, (wrong, quality)            # every dot and every line pixel where the reference has it
+    # how tight that is: sampled values close to a place where the drawing would have changed
+    m = refpics.decision_margins(u, v)
+    assert (m < 1e-3).sum() >= 5 and (m < 1e-2).sum() >= 50
+    # and how specific: each of these loses dozens of dots / lines
+    for label, (a, b, lam, it) in {"9 sweeps": (A, B, refpics.LAMBDA, 9), "11 sweeps": (A, B, refpics.LAMBDA, 11),
+                                   "lambda 0.09": (A, B, 0.09, 10), "lambda 0.11": (A, B, 0.11, 10),
+                                   "no blur": (A0, B0, refpics.LAMBDA, 10), "frames swapped": (B, A, refpics.LAMBDA, 10)}.items():
+        u2, v2 = cv_flow(oracle, a, b, lam, it)
+        wrong2, q2 = refpics.picture_difference(refpics.render(u2, v2), name)
+        assert wrong2 > 200 and q2 < 40.0, (label, wrong2, q2)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_the_opencl_route_pictures(oracle, name):
+    """Kernels.cl as shipped (v never written) vs oracle/hs_classic_oracle.c."""
+    pytest.importorskip("PIL")
+    A, B = refpics.gray_pair(name)
+    u, v = oracle.classic_flow(A, B, refpics.ALPHA, refpics.ITERATIONS, update_v=False)
+    assert not v.any()
+    wrong, quality = refpics.picture_difference(refpics.render(u, v, "cl"), name, "cl")
+    assert wrong == 0, (wrong, quality)
+    for label, (alpha, it, upd) in {"9 sweeps": (refpics.ALPHA, 9, False), "11 sweeps": (refpics.ALPHA, 11, False),
+                                    "alpha 14": (14.0, 10, False), "alpha 16": (16.0, 10, False),
+                                    "v update restored": (refpics.ALPHA, 10, True)}.items():
+        u2, v2 = oracle.classic_flow(A, B, alpha, it, update_v=upd)
+        wrong2, q2 = refpics.picture_difference(refpics.render(u2, v2, "cl"), name, "cl")
+        assert wrong2 > 200 and q2 < 40.0, (label, wrong2, q2)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_grid_decisions_without_a_jpeg_codec(oracle, name):
+    """Same check from the committed blue / red levels only (no PIL): all clear decisions agree but
+    the few points that long lines of neighbours overdraw."""
+    A0, B0 = refpics.gray_pair(name)
+    u, v = cv_flow(oracle, oracle.box_blur3(A0), oracle.box_blur3(B0))
+    bad, clear = refpics.compare_decisions(u, v, name)
+    assert clear > 0.99 * u[::4, ::4].size
+    assert bad <= (1 if name == "city" else 8), (bad, clear)
+    u9, v9 = cv_flow(oracle, oracle.box_blur3(A0), oracle.box_blur3(B0), it=9)
+    assert refpics.compare_decisions(u9, v9, name)[0] >= bad + 15
+
+
+def test_numpy_restatement_draws_the_same_picture(oracle):
+    from oracle import hs_numpy
+    A0, B0 = refpics.gray_pair("bunny")
+    A, B = oracle.box_blur3(A0), oracle.box_blur3(B0)
+    u, v = cv_flow(oracle, A, B)
+    u2, v2 = hs_numpy.calc_optical_flow_hs(A, B, refpics.LAMBDA, refpics.ITERATIONS, refpics.EPSILON, ITER_EPS)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
