@@ -104,6 +104,24 @@ __device__ __forceinline__ float wave_max(float x)
     return x;
 }
 
+// Maximum of a NON-NEGATIVE value over the wavefront, returned wave-uniform.  DPP only (no LDS
+// permutes): prefix-doubling row_shr 1/2/4/8 leaves each 16-lane row's maximum in its lane 15,
+// row_bcast:15 / row_bcast:31 carry it on to lane 63.  Lanes without a source read 0 (bound_ctrl,
+// old = 0), the identity for non-negative inputs.
+__device__ __forceinline__ float wave_max_nonneg(float x)
+{
+#define HS_DPP_MAX(ctrl, rowmask)                                                                  \
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rowmask, 0xF, true)))
+    HS_DPP_MAX(0x111, 0xF); // row_shr:1
+    HS_DPP_MAX(0x112, 0xF); // row_shr:2
+    HS_DPP_MAX(0x114, 0xF); // row_shr:4
+    HS_DPP_MAX(0x118, 0xF); // row_shr:8
+    HS_DPP_MAX(0x142, 0xA); // row_bcast:15 into rows 1 and 3
+    HS_DPP_MAX(0x143, 0xC); // row_bcast:31 into rows 2 and 3
+#undef HS_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
 // ------------------------------------------------------------------------------------------
 // a1: derivative pass, CV mode.  One lane = 4 consecutive pixels of one row.
 //     reads 2 B/pixel (u8 A with a 3x3 neighbourhood from L1/L2, u8 B), writes 4 B/pixel.
@@ -502,7 +520,7 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     vQ = f2_fma(-c.beQ, qQ, vbQ);
 }
 
-template <int R, int NTMAX, bool EPS>
+template <int R, int NTMAX, int EPS>
 __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
                                                         const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in,
@@ -510,10 +528,18 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         float *__restrict__ v_out, const StripGeom g,
                                                         const float ilambda,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
-                                                        unsigned long long *__restrict__ stamps)
+                                                        unsigned long long *__restrict__ stamps,
+                                                        const float eps_thr)
 {
-    // EPS: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over its
-    // core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
+    // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
+    // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
+    // EPS == 2 ("witness"): the cheap way to PROVE that no sweep of this launch had Eps < epsilon.
+    // At the end of a sweep a wavefront whose first row is a core row asks "did u change by >= eps_thr
+    // at column x0 of any lane of that row?" -- old and new value come back from the two exchange
+    // buffers, so nothing is kept in registers for it -- and counts the
+    // per-sweep answers in an SGPR.  Each |change| is a lower bound of that sweep's Eps, so a
+    // wavefront that answered yes in EVERY sweep proves Eps_k >= eps_thr for all k of the launch;
+    // eps_out[workgroup] = +inf if any wavefront of the workgroup did, else 0.
     // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
     // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
     // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hsflow.hip).
@@ -541,7 +567,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     // Workgroup-uniform: does the region (core + halo) stick out of the image on the left or right?
     // Tiles that do not (the vast majority) load with plain aligned 16-byte accesses only.
     const int rx0 = bx * g.CW - g.HX;
-    if (rx0 >= 0 && rx0 + 256 <= g.W) {
+    const bool xedge = !(rx0 >= 0 && rx0 + 256 <= g.W);
+    if (!xedge) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const long long off = base + (long long)mirror_index(y0 + r, g.H) * g.P + x0;
@@ -623,19 +650,29 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
     // sweeps skip it (wave-uniform branch), which trims the redundant halo work by about half.
 #ifdef HS_DIAG_NO_COMPUTE /* diagnostic build only: wrong results, times the exchange alone */
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ) do { uP[r] += UUP + DUP; } while (0)
+#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF) do { uP[r] += UUP + DUP; } while (0)
 #else
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
+#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF)                                      \
     do {                                                                                           \
         if (rdist[r] <= g.T - 1 - s) {                                                             \
             const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
-            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
+            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF);    \
             if (EPS) {                                                                             \
-                if (((rowcore >> r) & 1u) && lanecore) {                                           \
-                    e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
-                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
-                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ouQ.x - uQ[r].x), fabsf(ovQ.x - vQ[r].x))); \
-                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ouQ.y - uQ[r].y), fabsf(ovQ.y - vQ[r].y))); \
+                if ((rowcore >> r) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
+                    if (EPS == 1) {                                                                \
+                        const f2 dUP = ouP - uP[r], dUQ = ouQ - uQ[r], dVP = ovP - vP[r], dVQ = ovQ - vQ[r]; \
+                        if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
+                            e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                       \
+                            e = fmaxf(fmaxf(e, fabsf(dUQ.x)), fabsf(dUQ.y));                       \
+                            e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                       \
+                            e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                       \
+                        } else {                                                                   \
+                            e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                       \
+                            if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));          \
+                            if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));          \
+                            if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));          \
+                        }                                                                          \
+                    }                                                                              \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -665,6 +702,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
     const int wd = w < NW - 1 ? w + 1 : w, sd = w < NW - 1 ? 0 : 2; // strip below: its first row
     // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
+    int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
+                    // loop-carried flag makes the register allocator spill inside the loop)
 #pragma unroll 1
     for (int s = 0; s < g.T; s++) {
 #if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
@@ -679,45 +718,61 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
         const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
         float e = 0.f;
         if (R == 1) {
-            HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ);
+            HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ, cf[0]);
         } else {
             constexpr int R1 = R > 1 ? 1 : 0, RM = R > 2 ? R - 2 : 0;
             const f2 o0uP = uP[0], o0uQ = uQ[0], o0vP = vP[0], o0vQ = vQ[0];                 // old first row
             const f2 oNuP = uP[R - 1], oNuQ = uQ[R - 1], oNvP = vP[R - 1], oNvQ = vQ[R - 1]; // old last row
-            HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1]);
-            if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ);
-            else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ);
-            if (s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+            HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
+            if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
+            else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
+            if (EPS == 2 || s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
             f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
                 const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
                 const int rn = r + 1 < R ? r + 1 : r;
-                if (r + 1 == R - 1) HS_ROW(r, puP, puQ, pvP, pvQ, oNuP, oNuQ, oNvP, oNvQ);
-                else HS_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
+                if (r + 1 == R - 1) HS_ROW(r, puP, puQ, pvP, pvQ, oNuP, oNuQ, oNvP, oNvQ, cf[r]);
+                else HS_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn], cf[r]);
                 puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
             }
         }
-        if (R == 1 && s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
-        if (EPS) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
-            e = wave_max(e);
+        if (R == 1 && (EPS == 2 || s + 1 < g.T)) HS_PUBLISH((s + 1) & 1);
+        if (EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
+            e = wave_max_nonneg(lanecore ? e : 0.f);
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
                 float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
-                x = wave_max(x);
+                x = wave_max_nonneg(x);
                 if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
             }
+        }
+        if (EPS == 2 && (rowcore & 1u)) {
+            // witness, read back from the exchange buffers at the end of the sweep (no register is kept
+            // for it): slot 0 of this wavefront holds its first row of u, new in buffer (s+1)&1 and old
+            // in buffer s&1; component x is column x0, an image column wherever lanecore holds
+            const float nu = *(const float *)(ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane);
+            const float ou = *(const float *)(ex + ((size_t)((s & 1) * NW + w) * 4) * 64 + lane);
+            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
         }
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (s + 1 < g.T) __syncthreads();
 #endif
     }
-    if (EPS) {
+    if (EPS == 1) {
         __syncthreads();
         if (w == 0) {
             float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
-            x = wave_max(x);
+            x = wave_max_nonneg(x);
             if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+        }
+    }
+    if (EPS == 2) {
+        if (lane == 0) eps_lds[w] = (seen_n == g.T && (rowcore & 1u)) ? __builtin_inff() : 0.f;
+        __syncthreads();
+        if (w == 0) {
+            const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
+            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
         }
     }
 #undef HS_ROW

@@ -79,6 +79,9 @@ struct hsflow_ctx {
     unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
     unsigned *dEps = nullptr;   // kMaxFuse words: Eps sink of launches that do not collect it
     unsigned *epsPtr = nullptr; // where the running launch records Eps: [sweep][epsStride] words
+    float epsThr = 0.f;         // witness launches: smallest float >= epsilon
+    unsigned *hEps = nullptr;   // page-locked read-back buffer for the per-sweep Eps words
+    size_t hEpsCap = 0;
     int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
     unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
     size_t epsTilesCap = 0;
@@ -218,6 +221,7 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 // T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
 int strip_max_waves(int R, int fold) { const int r = fold ? R + 1 : R; return r <= 5 ? 16 : (r <= 6 ? 12 : 8); }
 
+
 double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double image_pixels, int *wg_per_cu_out = nullptr)
 {
     // Parameters fitted (least squares on log time, rms 8 %) to profiles/r01_sweep_1080p_strip5.csv,
@@ -300,11 +304,14 @@ int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fol
     return bestT;
 }
 
-template <int R, int NTMAX, bool EPS, bool FOLD>
+template <int R, int NTMAX, int EPS, bool FOLD> // EPS: 0 none, 1 every sweep, 2 witness (strip kernel only)
 hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                           float *uo, float *vo, float coeff, bool configure_only)
 {
-    auto kern = FOLD ? hsk::k_jacobi_fold<R, NTMAX, EPS> : hsk::k_jacobi_strip<R, NTMAX, EPS>;
+    auto kern = [] {
+        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS != 0>;
+        else return hsk::k_jacobi_strip<R, NTMAX, EPS>;
+    }();
     static bool configured[64] = {};
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -313,12 +320,16 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
         configured[c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr);
+    if constexpr (FOLD)
+        hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
+                           uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr);
+    else
+        hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
+                           uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
 }
 
-template <bool EPS, bool FOLD>
+template <int EPS, bool FOLD>
 hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                           float *uo, float *vo, float coeff, bool cfg)
 {
@@ -327,7 +338,9 @@ hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *
     case 2: return launch_strip_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 3: return launch_strip_t<3, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 4: return launch_strip_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
-    case 5: return launch_strip_t<5, FOLD ? 768 : 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5:
+        if (!FOLD && EPS && p.g.NW <= 12) return launch_strip_t<5, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+        return launch_strip_t<5, FOLD ? 768 : 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 6: return launch_strip_t<6, FOLD ? 512 : 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 7: return launch_strip_t<7, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 8: return launch_strip_t<8, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
@@ -344,20 +357,22 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
     return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
 }
 
-hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, bool eps, const float *ui, const float *vi,
+// eps: 0 none, 1 Eps of every sweep, 2 witness (strip kernel only: one lower bound per launch)
+hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *ui, const float *vi,
                     float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0)
 {
     if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         StripPlan sp = pl.s;
         sp.g.zero_in = zero_in;
-        if (sp.fold) return eps ? launch_strip_e<true, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
-                                : launch_strip_e<false, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
-        return eps ? launch_strip_e<true, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
-                   : launch_strip_e<false, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        if (sp.fold) return eps ? launch_strip_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                : launch_strip_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        return eps == 2 ? launch_strip_e<2, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+               : eps  ? launch_strip_e<1, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                      : launch_strip_e<0, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
     }
     FusedPlan fp = pl.f;
     fp.g.zero_in = zero_in;
-    return launch_fused(c, fp, eps, 1, ui, vi, uo, vo, coeff, cfg);
+    return launch_fused(c, fp, eps != 0, 1, ui, vi, uo, vo, coeff, cfg);
 }
 
 void plan_to_info(hsflow_ctx *c, const JPlan &pl)
@@ -509,9 +524,16 @@ int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
 {
     hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
     HS_HIP(c, hipGetLastError());
-    host.resize((size_t)sweeps);
-    HS_HIP(c, hipMemcpyAsync(host.data(), c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    if (c->hEpsCap < (size_t)sweeps) {
+        if (c->hEps) hipHostFree(c->hEps);
+        c->hEps = nullptr; c->hEpsCap = 0;
+        const size_t cap = std::max<size_t>(256, (size_t)sweeps * 2);
+        HS_HIP(c, hipHostMalloc((void **)&c->hEps, cap * sizeof(unsigned), hipHostMallocDefault));
+        c->hEpsCap = cap;
+    }
+    HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HS_HIP(c, hipStreamSynchronize(c->stream));
+    host.assign(c->hEps, c->hEps + sweeps);
     c->epsPtr = c->dEps;
     c->epsStride = 1;
     return HSFLOW_OK;
@@ -724,7 +746,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             if (!make_jplan(c, kernel, iters % T, p, tp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
             stride = std::max(stride, plan_eps_stride(kernel, tp));
         }
-        if ((st = eps_prepare(c, iters, stride))) return st;
+        if (kernel != HSFLOW_KERNEL_STRIP && (st = eps_prepare(c, iters, stride))) return st;
         if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
             prof.begin(0);
             HS_HIP(c, launch_deriv(c));
@@ -732,7 +754,64 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         }
         c->coef_valid = true;
         c->coef_mode = HSFLOW_MODE_CV;
-        int zero_in = p.use_previous ? 0 : 1, launches = 0, done = 0;
+        int launches = 0;
+        if (kernel == HSFLOW_KERNEL_STRIP) {
+            // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
+            // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
+            // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch measures every
+            // sweep (it also provides last_eps).  If every bound holds and no sweep of the last launch
+            // but possibly its final one fell below epsilon, the early stop cannot have fired before the
+            // budget ran out and the result stands.  Otherwise (a flat or converged input) the exact
+            // per-sweep path below starts over from the saved flow.
+            // threshold as the smallest float >= epsilon: "change >= epsThr" then implies "Eps >= epsilon"
+            c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
+            if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
+            const int n_launch = (iters + T - 1) / T;
+            const int last_chunk = iters - (n_launch - 1) * T;
+            const int slots = (n_launch - 1) + last_chunk;
+            if ((st = eps_prepare(c, slots, stride))) return st;
+            int zero_w = p.use_previous ? 0 : 1;
+            const int cur0 = c->cur;
+            if (zero_w) c->cur = 0;
+            for (int L = 0; L < n_launch; L++) {
+                const bool is_last = L == n_launch - 1;
+                const int chunk = is_last ? last_chunk : T;
+                JPlan cp = plan;
+                if (chunk != T && !make_jplan(c, kernel, chunk, p, cp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+                const int a = c->cur, b = a ^ 1;
+                c->epsPtr = c->dEpsTiles + (size_t)L * stride;
+                prof.begin(1);
+                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w);
+                prof.end();
+                HS_HIP(c, e);
+                c->cur = b;
+                zero_w = 0;
+                launches++;
+            }
+            std::vector<unsigned> hw;
+            if ((st = eps_collect(c, slots, hw))) return st;
+            bool proven = true;
+            float last = 0.f;
+            for (int i = 0; i < slots && proven; i++) {
+                std::memcpy(&last, &hw[(size_t)i], sizeof(float));
+                if (!((double)last >= p.epsilon) && i != slots - 1) proven = false; // a stop at the very last sweep = the budget
+            }
+            if (proven) {
+                c->info.iterations_done = iters;
+                c->info.last_eps = last;
+                c->info.jacobi_launches = launches;
+                prof.collect();
+                return HSFLOW_OK;
+            }
+            // not proven: restore the starting flow and measure every sweep
+            if (p.use_previous) {
+                c->cur = cur0;
+                HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            }
+            if ((st = eps_prepare(c, iters, stride))) return st;
+        }
+        int zero_in = p.use_previous ? 0 : 1, done = 0;
         if (zero_in) c->cur = 0;
         while (done < iters) {
             const int chunk = multi ? std::min(T, iters - done) : 1;
@@ -1012,6 +1091,7 @@ int hsflow_destroy(hsflow_ctx *c)
     hipFree(c->dEpsAll); hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
     hipFree(c->dScratch);
+    if (c->hEps) hipHostFree(c->hEps);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return HSFLOW_OK;

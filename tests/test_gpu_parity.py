@@ -373,3 +373,44 @@ def test_randomized_shapes_parameters_kernels(hs, oracle, gpu_ok):
                 ref = (u, v)
             else:
                 assert np.array_equal(u, ref[0]) and np.array_equal(v, ref[1]), (case, W, H, lam, it, kw)
+
+
+def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
+    """ITER|EPS on the strip kernel first runs "witness" launches that only PROVE Eps >= epsilon for
+    all their sweeps, and falls back to measuring every sweep when the proof fails.  Both regimes
+    must give the oracle's sweep count, Eps and flow."""
+    W, H, it = 700, 300, 57
+    A, B = synth.translating_pair(W, H, seed=21, dx=1.25, dy=-0.75)
+    eps6 = float(np.float32(1e-6))
+    uo, vo, n_o, e_o = oracle.calc_optical_flow_hs(A, B, 0.7, it, eps6, ITER | EPS, return_info=True)
+    assert n_o == it                                   # natural images never get below 1e-6 this early
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        plain = ctx.solve(lam=0.7, max_iter=it, term_type=ITER)
+        u0, v0 = ctx.flow()
+        fast = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS)
+        u1, v1 = ctx.flow()
+        assert fast["iterations_done"] == it and fast["jacobi_launches"] == plain["jacobi_launches"]  # proof held: no re-run
+        assert np.array_equal(u0, u1) and np.array_equal(v0, v1)
+        assert abs(fast["last_eps"] - e_o) <= 1e-3 * e_o
+        check("iter_eps_witness", (u1, v1), (uo, vo))
+        # epsilon just under the final Eps: whether or not the sampled lower bounds still clear it (if
+        # not, every sweep gets measured), the answer stays "budget reached"
+        for frac in (0.98, 0.999, 0.99999):
+            near = float(e_o) * frac
+            uo2, vo2, n2, e2 = oracle.calc_optical_flow_hs(A, B, 0.7, it, near, ITER | EPS, return_info=True)
+            slow = ctx.solve(lam=0.7, max_iter=it, epsilon=near, term_type=ITER | EPS)
+            u2, v2 = ctx.flow()
+            assert abs(slow["iterations_done"] - n2) <= 1, (frac, slow["iterations_done"], n2)
+            if slow["iterations_done"] == n2:
+                check("iter_eps_near_%g" % frac, (u2, v2), (uo2, vo2))
+        # epsilon above the final Eps: stops inside the budget, at the oracle's sweep
+        over = float(e_o) * 3.0
+        uo3, vo3, n3, e3 = oracle.calc_optical_flow_hs(A, B, 0.7, it, over, ITER | EPS, return_info=True)
+        assert n3 < it
+        stop = ctx.solve(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS)
+        u3, v3 = ctx.flow()
+        assert abs(stop["iterations_done"] - n3) <= 1
+        assert stop["jacobi_launches"] > plain["jacobi_launches"]          # witness pass + exact pass + re-run
+        if stop["iterations_done"] == n3:
+            check("iter_eps_early_stop", (u3, v3), (uo3, vo3))
