@@ -114,6 +114,8 @@ typedef struct hsflow_info {
     float deriv_ms;           /* profile=1: derivative kernel time                        */
     float jacobi_ms;          /* profile=1: sum of Jacobi kernel times                    */
     float solve_ms;           /* profile=1: first event to last event of the solve        */
+    int32_t eps_rerun;        /* ITER|EPS: 1 if the fast pass could not prove "no early stop"
+                                 and the solve was repeated with Eps measured in every sweep */
 } hsflow_info;
 
 /* --- lifecycle ---------------------------------------------------------------------------- */
@@ -156,8 +158,13 @@ int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t 
 /* --- solve -------------------------------------------------------------------------------- */
 
 /* Derivative pass + Jacobi iterations for every pair of the context.  hsflow_solve returns
- * after the device finished; hsflow_solve_async only enqueues (ITER-only termination, no
- * profile) and the caller synchronises the stream or calls hsflow_synchronize. */
+ * after the device finished; hsflow_solve_async only enqueues (no profile) and the caller
+ * synchronises the stream or calls hsflow_synchronize.  Asynchronous solves take ITER termination
+ * with any kernel, or ITER|EPS (the reference's call, OpticalFlowOpenCV.cpp:29) with the strip
+ * kernel: the early-stop check is then owed until hsflow_synchronize / hsflow_get_flow /
+ * hsflow_get_info / the next solve settles it -- if the fast pass cannot prove that the stop
+ * never fired, the solve is repeated exactly (hsflow_info.eps_rerun = 1), so flow copied out by
+ * an earlier hsflow_get_flow_async has to be fetched again in that case. */
 int hsflow_solve(hsflow_ctx *ctx, const hsflow_params *params);
 int hsflow_solve_async(hsflow_ctx *ctx, const hsflow_params *params);
 int hsflow_synchronize(hsflow_ctx *ctx);
@@ -210,7 +217,8 @@ int hsflow_host_unregister(void *p);
  * run beside the solve of pair i.  It replaces the per-pair body of the reference's run()
  * (HSOpticalFlowOpenCL.cpp:744-767: write frames, derivatives, iterations, read u, v).
  * The host buffers of a submitted pair belong to the pipeline until wait(ticket) returned; use
- * page-locked memory for them.  ITER-only termination (what hsflow_solve_async accepts).
+ * page-locked memory for them.  Termination: ITER, or ITER|EPS (strip kernel) -- whatever
+ * hsflow_solve_async accepts; a pair whose early stop fired is re-solved inside wait().
  * Single-owner like a context; one pipeline per (thread, device). */
 typedef struct hsflow_pipeline hsflow_pipeline;
 int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int height, int depth);
@@ -221,6 +229,9 @@ int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t prev
                            const uint8_t *curr, size_t curr_stride, float *u, size_t u_stride,
                            float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
 int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket); /* u, v of that pair are complete */
+/* wait(ticket) + iterations_done, last_eps, eps_rerun ... of that pair; HSFLOW_E_STATE once a later
+ * pair has finished on the same slot (ask before submitting `depth` more pairs). */
+int hsflow_pipeline_info(hsflow_pipeline *pl, uint64_t ticket, hsflow_info *info);
 int hsflow_pipeline_drain(hsflow_pipeline *pl);                 /* wait for everything submitted */
 int hsflow_pipeline_depth(hsflow_pipeline *pl);
 const char *hsflow_pipeline_last_error(hsflow_pipeline *pl);    /* pl may be NULL: create() error */

@@ -37,7 +37,7 @@ class HsflowInfo(ctypes.Structure):
                 ("groups_per_thread", ctypes.c_int32), ("tiles", ctypes.c_int32),
                 ("lds_bytes", ctypes.c_int32), ("jacobi_launches", ctypes.c_int32),
                 ("deriv_ms", ctypes.c_float), ("jacobi_ms", ctypes.c_float),
-                ("solve_ms", ctypes.c_float)]
+                ("solve_ms", ctypes.c_float), ("eps_rerun", ctypes.c_int32)]
 
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -76,6 +76,7 @@ PROTOTYPES = {
     "hsflow_pipeline_destroy": (_i, [_vp]),
     "hsflow_pipeline_submit": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
     "hsflow_pipeline_wait": (_i, [_vp, ctypes.c_uint64]),
+    "hsflow_pipeline_info": (_i, [_vp, ctypes.c_uint64, ctypes.POINTER(HsflowInfo)]),
     "hsflow_pipeline_drain": (_i, [_vp]),
     "hsflow_pipeline_depth": (_i, [_vp]),
     "hsflow_pipeline_last_error": (ctypes.c_char_p, [_vp]),

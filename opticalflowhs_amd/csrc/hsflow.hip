@@ -95,6 +95,13 @@ struct hsflow_ctx {
     bool coef_valid = false;
     hsflow_info info;
     std::string err;
+    // an ITER|EPS solve enqueued by hsflow_solve_async whose early-stop check is still owed
+    struct Pending {
+        bool active = false;
+        hsflow_params params;
+        int iters = 0, slots = 0, launches = 0, cur0 = 0;
+    } pend;
+    bool force_exact = false; // the exact per-sweep pass is wanted (set while a pending solve is settled)
     std::map<GraphKey, GraphEntry> graphs;
     std::vector<hipEvent_t> events;
 };
@@ -520,11 +527,12 @@ int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
     return HSFLOW_OK;
 }
 
-int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
+int eps_collect_enqueue(hsflow_ctx *c, int sweeps)
 {
     hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
     HS_HIP(c, hipGetLastError());
     if (c->hEpsCap < (size_t)sweeps) {
+        HS_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still write the old buffer
         if (c->hEps) hipHostFree(c->hEps);
         c->hEps = nullptr; c->hEpsCap = 0;
         const size_t cap = std::max<size_t>(256, (size_t)sweeps * 2);
@@ -532,11 +540,31 @@ int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
         c->hEpsCap = cap;
     }
     HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HS_HIP(c, hipStreamSynchronize(c->stream));
-    host.assign(c->hEps, c->hEps + sweeps);
     c->epsPtr = c->dEps;
     c->epsStride = 1;
     return HSFLOW_OK;
+}
+
+int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
+{
+    int st = eps_collect_enqueue(c, sweeps);
+    if (st) return st;
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    host.assign(c->hEps, c->hEps + sweeps);
+    return HSFLOW_OK;
+}
+
+// Witness slots of a speculative ITER|EPS pass (host copy): true if they prove that the early stop
+// cannot have fired before the budget ran out; *last = Eps of the final sweep.
+bool witness_proven(const unsigned *w, int slots, double epsilon, float *last)
+{
+    float e = 0.f;
+    for (int i = 0; i < slots; i++) {
+        std::memcpy(&e, &w[i], sizeof(float));
+        if (!((double)e >= epsilon) && i != slots - 1) return false; // a stop at the very last sweep = the budget
+    }
+    *last = e;
+    return true;
 }
 
 int plan_eps_stride(int kernel, const JPlan &pl) { return (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) ? pl.s.tiles : 1; }
@@ -622,10 +650,43 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     return HSFLOW_OK;
 }
 
+int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async);
+
+// Settles an ITER|EPS solve that hsflow_solve_async left unverified: waits for the stream, looks at the
+// witness words and, if they do not prove "no early stop", runs the exact pass from the saved start.
+int settle_pending(hsflow_ctx *c)
+{
+    if (!c->pend.active) return HSFLOW_OK;
+    c->pend.active = false;
+    HS_HIP(c, hipSetDevice(c->device));
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    float last = 0.f;
+    if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last)) {
+        c->info.iterations_done = c->pend.iters;
+        c->info.last_eps = last;
+        return HSFLOW_OK;
+    }
+    hsflow_params q = c->pend.params;
+    q.reuse_derivatives = 1; // the coefficient plane of that solve is still in place
+    if (q.use_previous) {
+        const size_t px = (size_t)c->plane * c->N;
+        c->cur = c->pend.cur0;
+        HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->force_exact = true;
+    const int st = solve_impl(c, &q, false);
+    c->force_exact = false;
+    c->info.eps_rerun = 1;
+    c->info.jacobi_launches += c->pend.launches;
+    return st;
+}
+
 int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
 {
     int st = check_ctx(c, 0);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve comes first
     if (!pp || pp->struct_size != sizeof(hsflow_params))
         return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
     const hsflow_params &p = *pp;
@@ -637,8 +698,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     if (use_iter && p.max_iter <= 0 && !use_eps)
         return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
     if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
-    if (async && (use_eps || p.profile))
-        return fail(c, HSFLOW_E_ARG, "solve_async supports ITER-only termination without profiling");
+    if (async && p.profile) return fail(c, HSFLOW_E_ARG, "solve_async does not support profiling");
+    c->info.eps_rerun = 0;
 
     const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
     const int kernel = p.kernel == HSFLOW_KERNEL_AUTO ? HSFLOW_KERNEL_STRIP : p.kernel;
@@ -646,6 +707,9 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         kernel != HSFLOW_KERNEL_FOLD)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
     const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
+    if (async && use_eps && !(use_iter && p.max_iter > 0 && p.max_iter <= (1 << 16) && kernel == HSFLOW_KERNEL_STRIP && !c->force_exact))
+        return fail(c, HSFLOW_E_ARG, "solve_async with EPS termination needs ITER|EPS with a sweep budget and the strip kernel "
+                                     "(ITER-only termination works with every kernel)");
     // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
     // EPS-only runs use chunks until Eps < epsilon.
     const long long budget = (use_iter && p.max_iter > 0) ? p.max_iter : (1LL << 40);
@@ -746,7 +810,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             if (!make_jplan(c, kernel, iters % T, p, tp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
             stride = std::max(stride, plan_eps_stride(kernel, tp));
         }
-        if (kernel != HSFLOW_KERNEL_STRIP && (st = eps_prepare(c, iters, stride))) return st;
+        if ((kernel != HSFLOW_KERNEL_STRIP || c->force_exact) && (st = eps_prepare(c, iters, stride))) return st;
         if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
             prof.begin(0);
             HS_HIP(c, launch_deriv(c));
@@ -755,7 +819,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         c->coef_valid = true;
         c->coef_mode = HSFLOW_MODE_CV;
         int launches = 0;
-        if (kernel == HSFLOW_KERNEL_STRIP) {
+        if (kernel == HSFLOW_KERNEL_STRIP && !c->force_exact) {
             // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
             // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
             // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch measures every
@@ -788,21 +852,26 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                 zero_w = 0;
                 launches++;
             }
+            if (async) { // the check is owed: hsflow_synchronize (or the next call that needs results) settles it
+                if ((st = eps_collect_enqueue(c, slots))) return st;
+                c->pend.active = true;
+                c->pend.params = p;
+                c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
+                c->info.iterations_done = iters;
+                c->info.jacobi_launches = launches;
+                return HSFLOW_OK;
+            }
             std::vector<unsigned> hw;
             if ((st = eps_collect(c, slots, hw))) return st;
-            bool proven = true;
             float last = 0.f;
-            for (int i = 0; i < slots && proven; i++) {
-                std::memcpy(&last, &hw[(size_t)i], sizeof(float));
-                if (!((double)last >= p.epsilon) && i != slots - 1) proven = false; // a stop at the very last sweep = the budget
-            }
-            if (proven) {
+            if (witness_proven(hw.data(), slots, p.epsilon, &last)) {
                 c->info.iterations_done = iters;
                 c->info.last_eps = last;
                 c->info.jacobi_launches = launches;
                 prof.collect();
                 return HSFLOW_OK;
             }
+            c->info.eps_rerun = 1;
             // not proven: restore the starting flow and measure every sweep
             if (p.use_previous) {
                 c->cur = cur0;
@@ -1219,6 +1288,7 @@ int hsflow_synchronize(hsflow_ctx *c)
 {
     int st = check_ctx(c, 0);
     if (st) return st;
+    if ((st = settle_pending(c))) return st;
     HS_HIP(c, hipStreamSynchronize(c->stream));
     return HSFLOW_OK;
 }
@@ -1230,6 +1300,7 @@ int hsflow_get_flow(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size
     if (!u || !v) return fail(c, HSFLOW_E_ARG, "null flow pointer");
     const size_t rowb = (size_t)c->W * 4;
     if ((us & 3) || (vs & 3) || us < rowb || vs < rowb) return fail(c, HSFLOW_E_SIZE, "flow stride must be a multiple of 4 and >= 4*width");
+    if ((st = settle_pending(c))) return st;
     HS_HIP(c, hipStreamSynchronize(c->stream));
     HS_HIP(c, hipMemcpy2D(u, us, c->dU[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
     HS_HIP(c, hipMemcpy2D(v, vs, c->dV[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
@@ -1330,6 +1401,8 @@ int hsflow_get_info(hsflow_ctx *c, hsflow_info *info)
 {
     if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
     if (!info || info->struct_size != sizeof(hsflow_info)) return fail(c, HSFLOW_E_ARG, "info null or struct_size mismatch");
+    const int st = settle_pending(c); // iterations_done / last_eps of an asynchronous ITER|EPS solve
+    if (st) return st;
     *info = c->info;
     return HSFLOW_OK;
 }

@@ -17,6 +17,11 @@ struct hsflow_pipeline {
         hsflow_ctx *ctx = nullptr;
         bool busy = false;
         uint64_t ticket = 0;
+        float *u = nullptr, *v = nullptr; // where the running job's flow goes
+        size_t us = 0, vs = 0;
+        hsflow_info done;                 // of the last job that finished on this slot
+        bool has_done = false;
+        uint64_t done_ticket = 0;
     };
     std::vector<Slot> slots;
     uint64_t next = 0;
@@ -43,8 +48,16 @@ int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
 {
     if (!s.busy) return HSFLOW_OK;
     s.busy = false; // also on failure: the job is over either way
-    const int st = hsflow_synchronize(s.ctx);
-    return st ? ctx_fail(pl, s.ctx, st, "hsflow_synchronize") : HSFLOW_OK;
+    int st = hsflow_synchronize(s.ctx); // also settles the early-stop check of an ITER|EPS solve
+    if (st) return ctx_fail(pl, s.ctx, st, "hsflow_synchronize");
+    hsflow_info info;
+    info.struct_size = sizeof(info);
+    if ((st = hsflow_get_info(s.ctx, &info))) return ctx_fail(pl, s.ctx, st, "hsflow_get_info");
+    if (info.eps_rerun) { // the solve was repeated exactly: what the queued download copied is stale
+        if ((st = hsflow_get_flow(s.ctx, 0, s.u, s.us, s.v, s.vs))) return ctx_fail(pl, s.ctx, st, "hsflow_get_flow");
+    }
+    s.done = info; s.has_done = true; s.done_ticket = s.ticket;
+    return HSFLOW_OK;
 }
 
 } // namespace
@@ -99,6 +112,7 @@ int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t ps, 
     }
     s.busy = true;
     s.ticket = pl->next;
+    s.u = u; s.v = v; s.us = us; s.vs = vs;
     if (ticket) *ticket = pl->next;
     pl->next++;
     return HSFLOW_OK;
@@ -112,6 +126,18 @@ int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket)
     // a later job on the same slot means this one was already waited for inside submit()
     if (!s.busy || s.ticket != ticket) return HSFLOW_OK;
     return finish_slot(pl, s);
+}
+
+int hsflow_pipeline_info(hsflow_pipeline *pl, uint64_t ticket, hsflow_info *out)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    if (!out || out->struct_size != sizeof(hsflow_info)) return pfail(pl, HSFLOW_E_ARG, "info null or struct_size mismatch");
+    int st = hsflow_pipeline_wait(pl, ticket);
+    if (st) return st;
+    const hsflow_pipeline::Slot &s = pl->slots[ticket % pl->slots.size()];
+    if (!s.has_done || s.done_ticket != ticket) return pfail(pl, HSFLOW_E_STATE, "the slot of that ticket has been reused by a later pair");
+    *out = s.done;
+    return HSFLOW_OK;
 }
 
 int hsflow_pipeline_drain(hsflow_pipeline *pl)

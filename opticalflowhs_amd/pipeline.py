@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 from . import _lib
-from ._lib import HsflowError, TERM_ITER
+from ._lib import HsflowError, HsflowInfo, TERM_ITER
 from .solver import make_params
 
 
@@ -30,7 +30,7 @@ def pinned_empty(shape, dtype):
 
 
 class PairPipeline(object):
-    """`depth` single-pair contexts used round-robin; ITER-only termination."""
+    """`depth` single-pair contexts used round-robin.  Termination: ITER (default) or ITER|EPS."""
 
     def __init__(self, width, height, depth=4, device=0):
         self._lib = _lib.load()
@@ -70,6 +70,14 @@ class PairPipeline(object):
     def wait(self, ticket):
         self._check(self._lib.hsflow_pipeline_wait(self._h, int(ticket)))
         self._held.pop(int(ticket), None)
+
+    def info(self, ticket):
+        """wait(ticket) + the solver's report for that pair (iterations_done, last_eps, eps_rerun, ...)."""
+        i = HsflowInfo()
+        i.struct_size = ctypes.sizeof(HsflowInfo)
+        self._check(self._lib.hsflow_pipeline_info(self._h, int(ticket), ctypes.byref(i)))
+        self._held.pop(int(ticket), None)
+        return {name: getattr(i, name) for name, _ in HsflowInfo._fields_}
 
     def drain(self):
         self._check(self._lib.hsflow_pipeline_drain(self._h))

@@ -85,9 +85,12 @@ def test_pipeline_errors(hs, gpu_ok):
     A, B = synth.random_pair(W, H, seed=5)
     u, v = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
     with hs.PairPipeline(W, H, depth=2) as pl:
-        with pytest.raises(hs.HsflowError) as e:      # EPS termination needs the host in the loop
-            pl.submit(A, B, u, v, lam=1.0, max_iter=5, term_type=hs.TERM_ITER | hs.TERM_EPS)
-        assert e.value.status == hs._lib.E_ARG and "ITER-only" in str(e.value)
+        with pytest.raises(hs.HsflowError) as e:      # EPS alone needs the host between chunks
+            pl.submit(A, B, u, v, lam=1.0, max_iter=5, term_type=hs.TERM_EPS)
+        assert e.value.status == hs._lib.E_ARG and "ITER|EPS" in str(e.value)
+        with pytest.raises(hs.HsflowError) as e:      # ... and ITER|EPS is asynchronous on the strip kernel only
+            pl.submit(A, B, u, v, lam=1.0, max_iter=5, term_type=hs.TERM_ITER | hs.TERM_EPS, kernel=hs.KERNEL_FUSED)
+        assert e.value.status == hs._lib.E_ARG
         with pytest.raises(hs.HsflowError) as e:
             pl.wait(0)                                # nothing was issued
         assert e.value.status == hs._lib.E_ARG
@@ -100,3 +103,57 @@ def test_pipeline_errors(hs, gpu_ok):
         pl.wait(t)
         pl.wait(t)                                    # idempotent
         assert np.isfinite(u).all() and np.abs(u).max() > 0
+
+
+def test_pipeline_iter_eps_like_the_reference_call(hs, oracle, gpu_ok):
+    """cvCalcOpticalFlowHS(.., ITER|EPS, it, 1e-6) per pair through the pipeline: pairs whose early
+    stop never fires stay on the fast path, a pair that converges at once is re-solved inside wait();
+    both must equal the synchronous solve and report its sweep count."""
+    W, H, it = 260, 140, 45
+    eps6 = float(np.float32(1e-6))
+    pairs = _pairs(5, W, H)
+    flat = np.full((H, W), 77, np.uint8)
+    pairs.insert(2, (flat, flat.copy()))               # identical frames: Eps = 0 after the first sweep
+    ref = []
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        for A, B in pairs:
+            ctx.set_frames(A, B)
+            info = ctx.solve(lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+            ref.append((ctx.flow(), info["iterations_done"], info["last_eps"]))
+        # the asynchronous form on a plain context: results are final after synchronize()
+        ctx.set_frames(*pairs[0])
+        ctx.solve_async(lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+        ctx.synchronize()
+        i0 = ctx.info()
+        assert i0["iterations_done"] == ref[0][1] and i0["eps_rerun"] == 0 and i0["last_eps"] == ref[0][2]
+        assert np.array_equal(ctx.flow()[0], ref[0][0][0])
+        ctx.set_frames(*pairs[2])
+        ctx.solve_async(lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+        u, v = ctx.flow()                               # settles the owed check, then copies
+        i2 = ctx.info()
+        assert i2["iterations_done"] == 1 and i2["eps_rerun"] == 1 and not u.any() and not v.any()
+    assert ref[2][1] == 1 and all(r[1] == it for k, r in enumerate(ref) if k != 2)
+    with hs.PairPipeline(W, H, depth=3) as pl:
+        outs = []
+        for A, B in pairs:
+            a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)
+            a[...], b[...] = A, B
+            u, v = hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)
+            u.fill(np.nan)
+            v.fill(np.nan)
+            t = pl.submit(a, b, u, v, lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+            outs.append((t, u, v))
+            if t >= 2:                                  # ask while the slot still remembers that pair
+                k = t - 2
+                info = pl.info(k)
+                assert info["iterations_done"] == ref[k][1] and info["eps_rerun"] == (1 if k == 2 else 0), (k, info)
+                assert np.array_equal(outs[k][1], ref[k][0][0]) and np.array_equal(outs[k][2], ref[k][0][1]), k
+        pl.drain()
+        for k in (len(pairs) - 2, len(pairs) - 1):
+            assert np.array_equal(outs[k][1], ref[k][0][0]) and np.array_equal(outs[k][2], ref[k][0][1]), k
+        with pytest.raises(hs.HsflowError) as e:        # slot long since reused
+            pl.info(0)
+        assert e.value.status == hs._lib.E_STATE
+    uo, vo, n_o, _ = oracle.calc_optical_flow_hs(pairs[1][0], pairs[1][1], 0.3, it, eps6, 3, return_info=True)
+    assert n_o == ref[1][1]
+    assert np.sqrt(np.mean((outs[1][1].astype(np.float64) - uo) ** 2)) <= RMS_TOL
