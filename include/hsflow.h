@@ -239,12 +239,17 @@ const char *hsflow_pipeline_last_error(hsflow_pipeline *pl);    /* pl may be NUL
 /* --- one-shot ------------------------------------------------------------------------------ */
 
 /* Same argument list as OpenCV's inner routine behind cvCalcOpticalFlowHS: strides in bytes,
- * term_type/max_iter/epsilon = CvTermCriteria.  Creates a context on device 0, uploads, solves,
- * downloads, destroys.  use_previous != 0 reads velx/vely as the starting flow. */
+ * term_type/max_iter/epsilon = CvTermCriteria.  Uploads, solves and downloads on device 0, on a
+ * context the library keeps between calls while width and height stay the same (the reference
+ * calls cvCalcOpticalFlowHS once per camera frame, OpticalFlowOpenCV.cpp:94); serialised by a
+ * mutex.  use_previous != 0 reads velx/vely as the starting flow. */
 int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, int img_step,
                                       int width, int height, int use_previous, float *velx,
                                       float *vely, int vel_step, float lambda, int term_type,
                                       int max_iter, double epsilon);
+
+/* Frees the context kept by hsflow_calc_optical_flow_hs_8u32f (optional; e.g. before unloading). */
+void hsflow_release_cached(void);
 
 #ifdef __cplusplus
 }

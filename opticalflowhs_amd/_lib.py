@@ -68,6 +68,7 @@ PROTOTYPES = {
     "hsflow_status_string": (ctypes.c_char_p, [_i]),
     "hsflow_version": (_i, []),
     "hsflow_device_count": (_i, [ctypes.POINTER(_i)]),
+    "hsflow_release_cached": (None, []),
     "hsflow_host_alloc": (_i, [ctypes.POINTER(_vp), _sz]),
     "hsflow_host_free": (_i, [_vp]),
     "hsflow_host_register": (_i, [_vp, _sz]),

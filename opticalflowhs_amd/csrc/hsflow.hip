@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -107,6 +108,9 @@ struct hsflow_ctx {
 };
 
 namespace {
+
+hsflow_ctx *g_oneshot = nullptr; // context kept by hsflow_calc_optical_flow_hs_8u32f between calls
+std::mutex g_oneshot_mutex;
 
 int fail(hsflow_ctx *c, int code, const std::string &msg)
 {
@@ -1415,9 +1419,18 @@ int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, 
     if (!prev || !curr || !velx || !vely) return fail(nullptr, HSFLOW_E_ARG, "null pointer");
     if (width <= 0 || height <= 0 || width > img_step || (vel_step & 3) || width * 4 > vel_step)
         return fail(nullptr, HSFLOW_E_SIZE, "bad size or step");
-    hsflow_ctx *c = nullptr;
-    int st = hsflow_create(&c, 0, width, height, 1, nullptr, 1);
-    if (st) return st;
+    // The reference calls cvCalcOpticalFlowHS once per frame of a stream (OpticalFlowOpenCV.cpp:94):
+    // building a context per call (7 device allocations, a stream) would cost several solves, so the
+    // one-shot form keeps the last context and reuses it while the frame size stays the same.
+    std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+    hsflow_ctx *c = g_oneshot;
+    int st = HSFLOW_OK;
+    if (!c || c->W != width || c->H != height) {
+        if (c) hsflow_destroy(c);
+        g_oneshot = c = nullptr;
+        if ((st = hsflow_create(&c, 0, width, height, 1, nullptr, 1))) return st;
+        g_oneshot = c;
+    }
     hsflow_params p;
     hsflow_default_params(&p);
     p.lambda = lambda; p.term_type = term_type; p.max_iter = max_iter; p.epsilon = epsilon;
@@ -1431,9 +1444,19 @@ int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, 
     }
     if (!st) st = hsflow_solve(c, &p);
     if (!st) st = hsflow_get_flow(c, 0, velx, (size_t)vel_step, vely, (size_t)vel_step);
-    if (st) g_create_error = c->err;
-    hsflow_destroy(c);
+    if (st) { // do not keep a context in an unknown state
+        g_create_error = c->err;
+        hsflow_destroy(c);
+        g_oneshot = nullptr;
+    }
     return st;
+}
+
+void hsflow_release_cached(void)
+{
+    std::lock_guard<std::mutex> lock(g_oneshot_mutex);
+    if (g_oneshot) hsflow_destroy(g_oneshot);
+    g_oneshot = nullptr;
 }
 
 } // extern "C"

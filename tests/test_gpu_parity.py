@@ -245,6 +245,40 @@ def test_strided_host_buffers_and_one_shot(hs, oracle, gpu_ok):
     hs.calc_optical_flow_hs(A, B, 0, vx, vy, 0.5, hs.term_criteria(ITER, 5, 0))
     hs.calc_optical_flow_hs(A, B, 1, vx, vy, 0.5, hs.term_criteria(ITER, 7, 0))
     check("mirror_use_previous", (vx, vy), (uo, vo))
+    # the one-shot keeps its context between calls: a stream of frames of one size, a size change, a
+    # warm start and an error in between must all behave like independent calls
+    import time
+    frames = [synth.random_pair(W, H, seed=40 + i) for i in range(3)]
+    t_first = t_later = 0.0
+    for i, (Ai, Bi) in enumerate(frames * 2):
+        vx2, vy2 = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+        t0 = time.perf_counter()
+        st = L.hsflow_calc_optical_flow_hs_8u32f(Ai.ctypes.data, Bi.ctypes.data, W, W, H, 0, vx2.ctypes.data, vy2.ctypes.data,
+                                                 W * 4, 0.5, ITER | EPS, 9, 1e-6)
+        dt = time.perf_counter() - t0
+        assert st == 0
+        ui, vi = oracle.calc_optical_flow_hs(Ai, Bi, 0.5, 9, 1e-6, ITER | EPS)
+        check("one_shot_stream_%d" % i, (vx2, vy2), (ui, vi))
+        if i > 0:
+            t_later += dt / 5
+    W2, H2 = 97, 31
+    A2, B2 = synth.random_pair(W2, H2, seed=50)
+    vx3, vy3 = np.zeros((H2, W2), np.float32), np.zeros((H2, W2), np.float32)
+    assert L.hsflow_calc_optical_flow_hs_8u32f(A2.ctypes.data, B2.ctypes.data, W2, W2, H2, 0, vx3.ctypes.data, vy3.ctypes.data,
+                                               W2 * 4, 2.0, ITER, 6, 0.0) == 0
+    u4, v4 = oracle.calc_optical_flow_hs(A2, B2, 2.0, 4, term_type=ITER)
+    vx4, vy4 = u4.copy(), v4.copy()                    # warm start from 4 sweeps, 2 more = 6 sweeps
+    assert L.hsflow_calc_optical_flow_hs_8u32f(A2.ctypes.data, B2.ctypes.data, W2, W2, H2, 1, vx4.ctypes.data, vy4.ctypes.data,
+                                               W2 * 4, 2.0, ITER, 2, 0.0) == 0
+    assert np.array_equal(vx4, vx3) or rms(vx4, vx3) < 1e-5
+    assert L.hsflow_calc_optical_flow_hs_8u32f(A2.ctypes.data, B2.ctypes.data, W2, W2, H2, 0, vx3.ctypes.data, vy3.ctypes.data,
+                                               W2 * 4, -1.0, ITER, 6, 0.0) == hs._lib.E_ARG   # bad lambda drops the context
+    assert L.hsflow_calc_optical_flow_hs_8u32f(A2.ctypes.data, B2.ctypes.data, W2, W2, H2, 0, vx3.ctypes.data, vy3.ctypes.data,
+                                               W2 * 4, 2.0, ITER, 6, 0.0) == 0
+    u6, v6 = oracle.calc_optical_flow_hs(A2, B2, 2.0, 6, term_type=ITER)
+    check("one_shot_after_error", (vx3, vy3), (u6, v6))
+    L.hsflow_release_cached()
+    L.hsflow_release_cached()                          # idempotent
 
 
 def test_error_statuses_on_gpu(hs, gpu_ok):
