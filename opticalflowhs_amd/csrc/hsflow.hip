@@ -222,6 +222,34 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 }
 
 
+template <int NT, int K>
+hipError_t launch_classic_fused_t(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
+                                  float *uo, float *vo, float alpha2)
+{
+    auto kern = write_v ? hsk::k_jacobi_classic_fused<NT, K, true> : hsk::k_jacobi_classic_fused<NT, K, false>;
+    static bool configured[2][64] = {};
+    if (p.lds_bytes > 32 * 1024 && !configured[write_v][c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[write_v][c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dE[0], c->dE[1], c->dE[2], ui, vi, uo, vo, p.g, alpha2);
+    return hipGetLastError();
+}
+
+hipError_t launch_classic_fused(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
+                                float *uo, float *vo, float alpha2)
+{
+#define HS_CASE(NT_, K_)                                                                          \
+    if (p.NT == NT_ && p.K == K_) return launch_classic_fused_t<NT_, K_>(c, p, write_v, ui, vi, uo, vo, alpha2);
+    HS_CASE(1024, 1) HS_CASE(1024, 2) HS_CASE(1024, 3)
+    HS_CASE(512, 1) HS_CASE(512, 2) HS_CASE(512, 3) HS_CASE(512, 4)
+    HS_CASE(256, 1) HS_CASE(256, 2) HS_CASE(256, 3) HS_CASE(256, 4)
+#undef HS_CASE
+    return hipErrorInvalidConfiguration;
+}
+
 // ------------------------------------------------------------------------------------------
 // Planner for the strip kernel: rows per lane R and wavefronts per workgroup NW.
 // Register budget fixes the wavefronts a SIMD can hold: R <= 5 -> 4, R = 6 -> 3, R <= 8 -> 2.
@@ -631,6 +659,43 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
     int zero = p.use_previous ? 0 : 1;
     if (zero) c->cur = 0;
+    if (p.kernel != HSFLOW_KERNEL_SIMPLE) {
+        // several sweeps per launch on an LDS tile (k_jacobi_classic_fused)
+        if (p.kernel != HSFLOW_KERNEL_AUTO && p.kernel != HSFLOW_KERNEL_FUSED)
+            return fail(c, HSFLOW_E_ARG, "CLASSIC mode has the simple and the fused (LDS tile) kernels only");
+        // 18 LDS values per plane and group and an IEEE division make a sweep dearer than in CV mode:
+        // the halo pays off up to about 6 sweeps per launch (tools/sweep_classic.py on MI355X)
+        const int T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
+        FusedPlan plan;
+        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, plan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
+        int done = 0, launches = 0;
+        while (done < p.max_iter) {
+            const int chunk = std::min(T, p.max_iter - done);
+            FusedPlan cp = plan;
+            if (chunk != T && !make_plan(c, chunk, p.tile_w, p.tile_h, p.threads, cp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible tile for the tail launch");
+            cp.g.zero_in = zero;
+            const int a = c->cur, b = a ^ 1;
+            prof.begin(1);
+            hipError_t e = launch_classic_fused(c, cp, write_v, c->dU[a], c->dV[a], c->dU[b], c->dV[b], a2);
+            prof.end();
+            HS_HIP(c, e);
+            c->cur = b;
+            zero = 0;
+            done += chunk;
+            launches++;
+        }
+        hsflow_info &i = c->info;
+        i.kernel = HSFLOW_KERNEL_FUSED; i.fuse_steps = T; i.tile_w = plan.g.CW; i.tile_h = plan.g.CH; i.threads = plan.NT;
+        i.groups_per_thread = plan.K; i.tiles = plan.tiles; i.lds_bytes = plan.lds_bytes; i.jacobi_launches = launches;
+        i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
+        if (!async) {
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            prof.collect();
+        }
+        return HSFLOW_OK;
+    }
     for (int it = 0; it < p.max_iter; it++) {
         const int a = c->cur, b = a ^ 1;
         prof.begin(1);

@@ -224,3 +224,43 @@ def test_hip_path_reproduces_the_opencl_route_pictures(hs, oracle, gpu_ok, tmp_p
     assert refpics.picture_difference(drawn, name, "cl")[0] == 0
     _cli(args, tmp_path)                                        # default: v update restored -> a different picture
     assert refpics.picture_difference(read_ppm(out), name, "cl")[0] > 200
+
+
+def test_classic_fused_kernel_equals_single_sweep_kernel(hs, oracle, gpu_ok):
+    """The multi-sweep LDS-tile kernel of the classic mode against the one-sweep kernel and the oracle,
+    bit for bit: tile / depth / workgroup variants, ragged sizes, several pairs, the as-shipped form."""
+    rng = np.random.default_rng(7)
+    for case, (W, H) in enumerate([(200, 120), (37, 29), (5, 3), (1, 9), (9, 1), (131, 67), (258, 64)]):
+        A, B = synth.translating_pair(W, H, seed=60 + case, dx=1.5, dy=-0.5) if min(W, H) > 8 else synth.random_pair(W, H, seed=60 + case)
+        it = int(rng.integers(1, 30))
+        alpha = float(rng.uniform(0.5, 20.0))
+        uo, vo = oracle.classic_flow(A, B, alpha, it)
+        us, vs = oracle.classic_flow(A, B, alpha, it, update_v=False)
+        with hs.HSFlow(W, H, own_stream=True) as ctx:
+            ctx.set_frames(A, B)
+            variants = [dict(kernel=hs.KERNEL_SIMPLE), dict(), dict(kernel=hs.KERNEL_FUSED, fuse_steps=1),
+                        dict(kernel=hs.KERNEL_FUSED, fuse_steps=int(rng.integers(2, 13))),
+                        dict(kernel=hs.KERNEL_FUSED, fuse_steps=4, tile_w=32, tile_h=8, threads=256),
+                        dict(kernel=hs.KERNEL_FUSED, fuse_steps=3, threads=512),
+                        dict(kernel=hs.KERNEL_FUSED, fuse_steps=6, threads=1024)]
+            for kw in variants:
+                info = ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, **kw)
+                u, v = ctx.flow()
+                assert info["iterations_done"] == it
+                assert np.array_equal(u, uo) and np.array_equal(v, vo), (W, H, it, alpha, kw, info)
+            info = ctx.solve(mode=hs.MODE_CLASSIC_AS_SHIPPED, alpha=alpha, max_iter=it, term_type=ITER)
+            u, v = ctx.flow()
+            assert info["kernel"] == hs.KERNEL_FUSED and np.array_equal(u, us) and not v.any()
+            with pytest.raises(hs.HsflowError):
+                ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP)
+    # a batch of pairs in one context
+    W, H, n = 96, 40, 3
+    with hs.HSFlow(W, H, n, own_stream=True) as ctx:
+        pairs = [synth.translating_pair(W, H, seed=80 + i) for i in range(n)]
+        for i, (A, B) in enumerate(pairs):
+            ctx.set_frames(A, B, pair=i)
+        ctx.solve(mode=hs.MODE_CLASSIC, alpha=4.0, max_iter=11, term_type=ITER)
+        for i, (A, B) in enumerate(pairs):
+            u, v = ctx.flow(pair=i)
+            uo, vo = oracle.classic_flow(A, B, 4.0, 11)
+            assert np.array_equal(u, uo) and np.array_equal(v, vo), i
