@@ -110,10 +110,11 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if args.iter_eps:  # the early-stop check needs one read-back per solve: synchronous, no graph
+    if args.iter_eps:  # the early-stop check needs one read-back per solve: synchronous solves
         p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER | hs.TERM_EPS,
                             epsilon=float(np.float32(1e-6)), kernel=kernel, fuse_steps=args.fuse_steps,
-                            tile_w=args.tile_w, tile_h=args.tile_h, threads=args.threads, strip_rows=args.strip_rows)
+                            tile_w=args.tile_w, tile_h=args.tile_h, threads=args.threads, strip_rows=args.strip_rows,
+                            use_graph=not args.no_graph)
         step = lambda: ctx.solve(p)
     else:
         step = lambda: ctx.solve_async(p)
@@ -170,7 +171,7 @@ def main():
                    "kernel": KNAME[info["kernel"]],
                    "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
                    "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
-                   "hipgraph": (not args.no_graph) and not args.iter_eps,
+                   "hipgraph": not args.no_graph,
                    "termination": "ITER|EPS (eps 1e-6)" if args.iter_eps else "ITER", "sharding": "independent pairs per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

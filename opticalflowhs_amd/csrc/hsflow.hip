@@ -51,10 +51,11 @@ struct JPlan {
 struct GraphKey {
     int mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev; // lr: K (fused) or R (strip)
     float coeff;
+    float eps_thr = -1.f; // >= 0: the graph of an ITER|EPS witness pass with that threshold
     bool operator<(const GraphKey &o) const
     {
-        return std::tie(mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev, coeff) <
-               std::tie(o.mode, o.kernel, o.max_iter, o.T, o.tw, o.th, o.nt, o.lr, o.cur, o.use_prev, o.coeff);
+        return std::tie(mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev, coeff, eps_thr) <
+               std::tie(o.mode, o.kernel, o.max_iter, o.T, o.tw, o.th, o.nt, o.lr, o.cur, o.use_prev, o.coeff, o.eps_thr);
     }
 };
 
@@ -539,7 +540,9 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
 
 // Eps bookkeeping of an EPS-terminated solve: `sweeps` rows of `stride` words, cleared, plus the
 // reduction of the rows into dEpsAll[0..sweeps).
-int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
+// Buffers for `sweeps` Eps words of `stride` workgroups each (device) and their host copy; allocation
+// only, so that what follows can be captured in a graph.
+int eps_reserve(hsflow_ctx *c, int sweeps, int stride)
 {
     const size_t need = (size_t)sweeps * stride;
     if (c->epsTilesCap < need) {
@@ -554,15 +557,6 @@ int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
         HS_HIP(c, hipMalloc((void **)&c->dEpsAll, (size_t)sweeps * sizeof(unsigned)));
         c->epsAllCap = sweeps;
     }
-    HS_HIP(c, hipMemsetAsync(c->dEpsTiles, 0, need * sizeof(unsigned), c->stream));
-    c->epsStride = stride;
-    return HSFLOW_OK;
-}
-
-int eps_collect_enqueue(hsflow_ctx *c, int sweeps)
-{
-    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
-    HS_HIP(c, hipGetLastError());
     if (c->hEpsCap < (size_t)sweeps) {
         HS_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still write the old buffer
         if (c->hEps) hipHostFree(c->hEps);
@@ -571,6 +565,26 @@ int eps_collect_enqueue(hsflow_ctx *c, int sweeps)
         HS_HIP(c, hipHostMalloc((void **)&c->hEps, cap * sizeof(unsigned), hipHostMallocDefault));
         c->hEpsCap = cap;
     }
+    c->epsStride = stride;
+    return HSFLOW_OK;
+}
+
+int eps_clear(hsflow_ctx *c, int sweeps, int stride)
+{
+    HS_HIP(c, hipMemsetAsync(c->dEpsTiles, 0, (size_t)sweeps * stride * sizeof(unsigned), c->stream));
+    return HSFLOW_OK;
+}
+
+int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
+{
+    const int st = eps_reserve(c, sweeps, stride);
+    return st ? st : eps_clear(c, sweeps, stride);
+}
+
+int eps_collect_enqueue(hsflow_ctx *c, int sweeps) // buffers from eps_reserve; nothing allocated here
+{
+    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
+    HS_HIP(c, hipGetLastError());
     HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->epsPtr = c->dEps;
     c->epsStride = 1;
@@ -866,29 +880,28 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     if (use_iter && p.max_iter > 0 && budget <= kSpecMax) {
         const int iters = (int)budget;
         const size_t px = (size_t)c->plane * c->N;
-        if (p.use_previous) { // keep the starting flow: the ping-pong buffers get overwritten
+        const bool witness = kernel == HSFLOW_KERNEL_STRIP && !c->force_exact;
+        const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
+        if (p.use_previous) { // the starting flow is kept: the ping-pong buffers get overwritten
             if (!c->dUb) HS_HIP(c, hipMalloc((void **)&c->dUb, px * sizeof(float)));
             if (!c->dVb) HS_HIP(c, hipMalloc((void **)&c->dVb, px * sizeof(float)));
+        }
+        auto save_start = [&]() -> int {
+            if (!p.use_previous) return HSFLOW_OK;
             HS_HIP(c, hipMemcpyAsync(c->dUb, c->dU[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
             HS_HIP(c, hipMemcpyAsync(c->dVb, c->dV[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        }
+            return HSFLOW_OK;
+        };
         // every launch of this solve uses the same number of workgroups or fewer (tail): stride = max
         int stride = multi ? plan_eps_stride(kernel, plan) : 1;
-        if (multi && iters % T) {
-            JPlan tp;
-            if (!make_jplan(c, kernel, iters % T, p, tp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
-            stride = std::max(stride, plan_eps_stride(kernel, tp));
+        JPlan tailp;
+        const bool has_tail = multi && iters % T;
+        if (has_tail) {
+            if (!make_jplan(c, kernel, iters % T, p, tailp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+            stride = std::max(stride, plan_eps_stride(kernel, tailp));
         }
-        if ((kernel != HSFLOW_KERNEL_STRIP || c->force_exact) && (st = eps_prepare(c, iters, stride))) return st;
-        if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
-            prof.begin(0);
-            HS_HIP(c, launch_deriv(c));
-            prof.end();
-        }
-        c->coef_valid = true;
-        c->coef_mode = HSFLOW_MODE_CV;
         int launches = 0;
-        if (kernel == HSFLOW_KERNEL_STRIP && !c->force_exact) {
+        if (witness) {
             // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
             // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
             // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch measures every
@@ -902,27 +915,72 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
             const int n_launch = (iters + T - 1) / T;
             const int last_chunk = iters - (n_launch - 1) * T;
             const int slots = (n_launch - 1) + last_chunk;
-            if ((st = eps_prepare(c, slots, stride))) return st;
-            int zero_w = p.use_previous ? 0 : 1;
+            if ((st = eps_reserve(c, slots, stride))) return st;
             const int cur0 = c->cur;
-            if (zero_w) c->cur = 0;
-            for (int L = 0; L < n_launch; L++) {
-                const bool is_last = L == n_launch - 1;
-                const int chunk = is_last ? last_chunk : T;
-                JPlan cp = plan;
-                if (chunk != T && !make_jplan(c, kernel, chunk, p, cp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
-                const int a = c->cur, b = a ^ 1;
-                c->epsPtr = c->dEpsTiles + (size_t)L * stride;
-                prof.begin(1);
-                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w);
-                prof.end();
-                HS_HIP(c, e);
-                c->cur = b;
-                zero_w = 0;
-                launches++;
+            // the whole pass as one enqueue sequence (nothing allocated, nothing synchronised: capturable)
+            auto enqueue = [&]() -> int {
+                int e0 = save_start();
+                if (e0) return e0;
+                c->epsStride = stride;
+                if ((e0 = eps_clear(c, slots, stride))) return e0;
+                if (do_deriv) {
+                    prof.begin(0);
+                    HS_HIP(c, launch_deriv(c));
+                    prof.end();
+                }
+                int zero_w = p.use_previous ? 0 : 1;
+                if (zero_w) c->cur = 0;
+                for (int L = 0; L < n_launch; L++) {
+                    const bool is_last = L == n_launch - 1;
+                    const JPlan &cp = (is_last && last_chunk != T) ? tailp : plan;
+                    const int a = c->cur, b = a ^ 1;
+                    c->epsPtr = c->dEpsTiles + (size_t)L * stride;
+                    prof.begin(1);
+                    hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w);
+                    prof.end();
+                    HS_HIP(c, e);
+                    c->cur = b;
+                    zero_w = 0;
+                    launches++;
+                }
+                return eps_collect_enqueue(c, slots);
+            };
+            if (p.use_graph && !p.profile) {
+                if (!c->stream)
+                    return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
+                                                 "context on a non-default stream or with own_stream");
+                GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+                             c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff, c->epsThr};
+                auto it = c->graphs.find(key);
+                if (it == c->graphs.end()) {
+                    // function attributes are set outside the capture
+                    HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                    HS_HIP(c, launch_j(c, plan, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                    if (has_tail) HS_HIP(c, launch_j(c, tailp, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                    HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                    st = enqueue();
+                    hipGraph_t graph = nullptr;
+                    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                    if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
+                    if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+                    GraphEntry ge{};
+                    ge.graph = graph;
+                    ge.cur_after = c->cur;
+                    ge.launches = launches;
+                    HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+                    it = c->graphs.emplace(key, ge).first;
+                }
+                HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
+                c->cur = it->second.cur_after;
+                launches = it->second.launches;
+                c->epsPtr = c->dEps;
+                c->epsStride = 1;
+            } else if ((st = enqueue())) {
+                return st;
             }
+            c->coef_valid = true;
+            c->coef_mode = HSFLOW_MODE_CV;
             if (async) { // the check is owed: hsflow_synchronize (or the next call that needs results) settles it
-                if ((st = eps_collect_enqueue(c, slots))) return st;
                 c->pend.active = true;
                 c->pend.params = p;
                 c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
@@ -930,8 +988,9 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                 c->info.jacobi_launches = launches;
                 return HSFLOW_OK;
             }
-            std::vector<unsigned> hw;
-            if ((st = eps_collect(c, slots, hw))) return st;
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            std::vector<unsigned> hw(c->hEps, c->hEps + slots);
+
             float last = 0.f;
             if (witness_proven(hw.data(), slots, p.epsilon, &last)) {
                 c->info.iterations_done = iters;
@@ -948,6 +1007,16 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                 HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
             }
             if ((st = eps_prepare(c, iters, stride))) return st;
+        } else {
+            if ((st = save_start())) return st;
+            if ((st = eps_prepare(c, iters, stride))) return st;
+            if (do_deriv) {
+                prof.begin(0);
+                HS_HIP(c, launch_deriv(c));
+                prof.end();
+            }
+            c->coef_valid = true;
+            c->coef_mode = HSFLOW_MODE_CV;
         }
         int zero_in = p.use_previous ? 0 : 1, done = 0;
         if (zero_in) c->cur = 0;

@@ -438,12 +438,23 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
             assert abs(slow["iterations_done"] - n2) <= 1, (frac, slow["iterations_done"], n2)
             if slow["iterations_done"] == n2:
                 check("iter_eps_near_%g" % frac, (u2, v2), (uo2, vo2))
+        # the same pass replayed from a hipGraph (kernels, Eps reduction and read-back in one graph)
+        for rep in range(3):
+            g = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, use_graph=True)
+            ug, vg = ctx.flow()
+            assert g["iterations_done"] == it and g["eps_rerun"] == 0 and g["last_eps"] == fast["last_eps"]
+            assert np.array_equal(ug, u1) and np.array_equal(vg, v1)
+        ctx.solve(lam=0.7, max_iter=5, term_type=ITER)
+        g2 = ctx.solve(lam=0.7, max_iter=it - 5, epsilon=eps6, term_type=ITER | EPS, use_graph=True, use_previous=True)
+        ug, vg = ctx.flow()
+        assert g2["iterations_done"] == it - 5 and np.array_equal(ug, u1) and np.array_equal(vg, v1)
         # epsilon above the final Eps: stops inside the budget, at the oracle's sweep
         over = float(e_o) * 3.0
         uo3, vo3, n3, e3 = oracle.calc_optical_flow_hs(A, B, 0.7, it, over, ITER | EPS, return_info=True)
         assert n3 < it
-        stop = ctx.solve(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS)
+        stop = ctx.solve(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS, use_graph=True)
         u3, v3 = ctx.flow()
+        assert stop["eps_rerun"] == 1
         assert abs(stop["iterations_done"] - n3) <= 1
         assert stop["jacobi_launches"] > plain["jacobi_launches"]          # witness pass + exact pass + re-run
         if stop["iterations_done"] == n3:
