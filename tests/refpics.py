@@ -21,9 +21,13 @@ another lambda / alpha, changes dozens of dots and lines (PSNR drops from identi
 What that pins: 24 360 (CPU route) + 24 360 (OpenCL route) drawn / not-drawn decisions and the
 integer end point of every drawn line, i.e. trunc(x + u/2), trunc(y + v/2) -- the pre-processing,
 the derivative scaling, the meaning of lambda / alpha, the sweep count, the update itself and the
-signs of u and v.  The tightest sampled points sit 6e-4 from a decision boundary, so the oracle
-agrees with OpenCV 2.1's cvCalcOpticalFlowHS (as run by the reference's authors) to better than
-1e-3 there; it is not an fp32-level vector.
+signs of u and v.  The tightest sampled points sit 1e-4 .. 6e-4 from a decision boundary, so the
+oracle agrees with OpenCV 2.1's cvCalcOpticalFlowHS (as run by the reference's authors) to better
+than 1e-3 there; it is not an fp32-level vector.  Neighbouring schemes are told apart
+(tests/variants.py, test_what_the_pictures_discriminate): Gauss-Seidel instead of Jacobi ordering,
+Sobel on frame B or on both frames, central differences, the 8-neighbour mean, lambda for 1/lambda
+each break > 5 000 pixels.  NOT told apart: the border rule of the mean (zero padding draws the same
+pictures after 10 sweeps) -- replicate there rests on the disassembly read alone.
 (Release/bunny_cl_out.jpg, a second OpenCL-route picture of the bunny pair, matches no scanned
 parameter pair of the shipped Kernels.cl -- best 27 dB -- and is not used.)
 """

@@ -71,3 +71,26 @@ def test_numpy_restatement_draws_the_same_picture(oracle):
     u, v = cv_flow(oracle, A, B)
     u2, v2 = hs_numpy.calc_optical_flow_hs(A, B, refpics.LAMBDA, refpics.ITERATIONS, refpics.EPSILON, ITER_EPS)
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_what_the_pictures_discriminate(oracle, name):
+    """Plausible neighbouring discretisations (tests/variants.py) against the CPU-route pictures: the
+    normative scheme is the oracle bit for bit and reproduces them; Gauss-Seidel ordering, derivatives
+    taken on the other / both frames or by central differences, the 8-neighbour mean and lambda instead
+    of 1/lambda each break thousands of pixels.  What the pictures do NOT see is the border rule of the
+    mean (zero padding draws the same picture after 10 sweeps): that one rests on the disassembly read."""
+    pytest.importorskip("PIL")
+    import variants
+    A0, B0 = refpics.gray_pair(name)
+    A, B = oracle.box_blur3(A0), oracle.box_blur3(B0)
+    uo, vo = cv_flow(oracle, A, B)
+    u, v = variants.flow(A, B, refpics.LAMBDA, refpics.ITERATIONS)
+    assert np.array_equal(u, uo) and np.array_equal(v, vo)
+    for kw in (dict(order="rows"), dict(derivative="sobelB"), dict(derivative="sobelAB"), dict(derivative="central"),
+               dict(mask=8), dict(regulariser="direct")):
+        u, v = variants.flow(A, B, refpics.LAMBDA, refpics.ITERATIONS, **kw)
+        wrong, quality = refpics.picture_difference(refpics.render(u, v), name)
+        assert wrong > 5000 and quality < 36.0, (kw, wrong, quality)
+    u, v = variants.flow(A, B, refpics.LAMBDA, refpics.ITERATIONS, border="zero")
+    assert refpics.picture_difference(refpics.render(u, v), name)[0] == 0   # not discriminated (see docstring)
