@@ -26,7 +26,8 @@ oracle agrees with OpenCV 2.1's cvCalcOpticalFlowHS (as run by the reference's a
 than 1e-3 there; it is not an fp32-level vector.  Neighbouring schemes are told apart
 (tests/variants.py, test_what_the_pictures_discriminate): Gauss-Seidel instead of Jacobi ordering,
 Sobel on frame B or on both frames, central differences, the 8-neighbour mean, lambda for 1/lambda
-each break > 5 000 pixels.  NOT told apart: the border rule of the mean (zero padding draws the same
+each break > 5 000 pixels; zero or mirrored borders for the Sobel stencil or the blur break the
+bunny picture.  NOT told apart: the border rule of the mean (zero padding draws the same
 pictures after 10 sweeps) -- replicate there rests on the disassembly read alone.
 (Release/bunny_cl_out.jpg, a second OpenCL-route picture of the bunny pair, matches no scanned
 parameter pair of the shipped Kernels.cl -- best 27 dB -- and is not used.)

@@ -78,8 +78,10 @@ def test_what_the_pictures_discriminate(oracle, name):
     """Plausible neighbouring discretisations (tests/variants.py) against the CPU-route pictures: the
     normative scheme is the oracle bit for bit and reproduces them; Gauss-Seidel ordering, derivatives
     taken on the other / both frames or by central differences, the 8-neighbour mean and lambda instead
-    of 1/lambda each break thousands of pixels.  What the pictures do NOT see is the border rule of the
-    mean (zero padding draws the same picture after 10 sweeps): that one rests on the disassembly read."""
+    of 1/lambda each break thousands of pixels; the bunny picture also tells the replicate border of the
+    Sobel stencil and of the blur from zero or mirrored borders.  What the pictures do NOT see is the
+    border rule of the mean (zero padding draws the same picture after 10 sweeps): that one rests on the
+    disassembly read."""
     pytest.importorskip("PIL")
     import variants
     A0, B0 = refpics.gray_pair(name)
@@ -94,3 +96,10 @@ def test_what_the_pictures_discriminate(oracle, name):
         assert wrong > 5000 and quality < 36.0, (kw, wrong, quality)
     u, v = variants.flow(A, B, refpics.LAMBDA, refpics.ITERATIONS, border="zero")
     assert refpics.picture_difference(refpics.render(u, v), name)[0] == 0   # not discriminated (see docstring)
+    if name == "bunny":  # its flow reaches the frame border: the border rules of Sobel and of the blur show
+        assert np.array_equal(variants.box_blur3(A0), A)
+        for pad in ("constant", "reflect"):
+            u, v = variants.flow(A, B, refpics.LAMBDA, refpics.ITERATIONS, derivative_pad=pad)
+            assert refpics.picture_difference(refpics.render(u, v), name)[0] > 100, pad
+            u, v = variants.flow(variants.box_blur3(A0, pad), variants.box_blur3(B0, pad), refpics.LAMBDA, refpics.ITERATIONS)
+            assert refpics.picture_difference(refpics.render(u, v), name)[0] > 100, pad

@@ -4,8 +4,8 @@ deviations from the normative scheme of SURVEY.md 8c; none of this is used by th
 import numpy as np
 
 
-def _sobel8(A):
-    a = np.pad(A.astype(np.int32), 1, mode="edge")
+def _sobel8(A, pad="edge"):
+    a = np.pad(A.astype(np.int32), 1, mode=pad)
     sv = a[:-2, :] + 2 * a[1:-1, :] + a[2:, :]
     sh = a[:, :-2] + 2 * a[:, 1:-1] + a[:, 2:]
     ix = (sv[:, 2:] - sv[:, :-2]).astype(np.float32) * np.float32(0.125)
@@ -28,13 +28,22 @@ def _mean(p, mask, border):
     return (s4 / 6.0 + s8 / 12.0).astype(np.float32)
 
 
-def flow(A, B, lam, iters, derivative="sobelA", mask=4, border="replicate", order="jacobi", regulariser="inverse"):
+def box_blur3(img, pad="edge"):
+    """3x3 mean, round half to even; pad = edge (cvSmooth's replicate, normative) | reflect | constant."""
+    a = np.pad(img.astype(np.int32), 1, mode=pad)
+    H, W = img.shape
+    s = sum(a[1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+    return np.asarray(np.rint(s / 9.0), dtype=np.uint8)
+
+
+def flow(A, B, lam, iters, derivative="sobelA", mask=4, border="replicate", order="jacobi", regulariser="inverse",
+         derivative_pad="edge"):
     """derivative: sobelA (normative) | sobelB | sobelAB (mean of both frames) | central (on A);
     mask: 4 (normative) | 8 (1/6, 1/12);  border of the mean: replicate (normative) | zero;
     order: jacobi (normative) | rows (Gauss-Seidel over rows: a row sees the new row above);
     regulariser: inverse (1/lambda, normative) | direct (lambda)."""
     if derivative == "sobelA":
-        ix, iy = _sobel8(A)
+        ix, iy = _sobel8(A, derivative_pad)  # edge (replicate, normative) | constant (zero) | reflect
     elif derivative == "sobelB":
         ix, iy = _sobel8(B)
     elif derivative == "sobelAB":
