@@ -550,6 +550,17 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = g.NW;
     float *eps_lds = (float *)(ex + (size_t)2 * NW * 4 * 64);
+    // Synchronisation between sweeps: ONE workgroup barrier per sweep.  Experiment kept behind
+    // HS_STRIP_P2P (default 0, measured SLOWER: 0.220 vs 0.200 ms at 1080p / 100 sweeps): a wavefront only
+    // depends on the strips directly above and below, so each wavefront raises a counter in LDS once its
+    // edge rows of a sweep are published and waits only for its two neighbours' counters.  LDS executes a
+    // wavefront's requests in order, so "counter >= s" implies that neighbour's rows for sweep s are in
+    // place AND that its reads of the buffer about to be overwritten are done (they precede its publish).
+#ifndef HS_STRIP_P2P
+#define HS_STRIP_P2P 0
+#endif
+    constexpr bool P2P = HS_STRIP_P2P && EPS != 1; // the per-sweep Eps fold of EPS == 1 relies on the barrier
+    volatile unsigned *flags = (volatile unsigned *)(eps_lds + 32); // [NW] sweeps published so far
     const int tpp = g.tiles_x * g.tiles_y;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const int pair = tile / tpp;
@@ -692,11 +703,20 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     } while (0)
 #endif
 
+#define HS_RAISE(n)                                                                                \
+    do {                                                                                           \
+        if (P2P) {                                                                                 \
+            asm volatile("" ::: "memory"); /* the rows first (LDS keeps a wavefront's order) */    \
+            if (lane == 0) flags[w] = (unsigned)(n);                                               \
+        }                                                                                          \
+    } while (0)
+
     // Exchange slots: ex[buf][wave][0..3][lane] = {first row u, first row v, last row u, last row v}.
     // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
     // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
     // LDS writes drain while the interior rows are being computed.
     HS_PUBLISH(0);
+    if (P2P && threadIdx.x < NW) flags[threadIdx.x] = 0;
     __syncthreads();
     if (stamps) st1 = __builtin_amdgcn_s_memtime();
     const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
@@ -711,8 +731,23 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
 #else
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
         const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
-        const float4 hu4 = eu[0], hv4 = eu[64];   // old row above the strip
-        const float4 du4 = ed[0], dv4 = ed[64];   // old row below the strip
+        float4 hu4, hv4, du4, dv4;
+        if (P2P) {
+            // counters first, rows right behind them in the same batch of LDS reads: if the counters
+            // (read earlier) say "published", the rows (read later) are the published ones; otherwise
+            // the batch is simply repeated
+            for (;;) {
+                asm volatile("" ::: "memory");
+                const unsigned fa = flags[wu], fb = flags[wd];
+                hu4 = eu[0]; hv4 = eu[64];   // old row above the strip
+                du4 = ed[0]; dv4 = ed[64];   // old row below the strip
+                if (fa >= (unsigned)s && fb >= (unsigned)s) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            hu4 = eu[0]; hv4 = eu[64];
+            du4 = ed[0]; dv4 = ed[64];
+        }
 #endif
         const f2 huP = f2{hu4.x, hu4.y}, huQ = f2{hu4.z, hu4.w}, hvP = f2{hv4.x, hv4.y}, hvQ = f2{hv4.z, hv4.w};
         const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
@@ -726,7 +761,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
             HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
             if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
             else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
-            if (EPS == 2 || s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+            if (EPS == 2 || s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
             f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
@@ -737,7 +772,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
             }
         }
-        if (R == 1 && (EPS == 2 || s + 1 < g.T)) HS_PUBLISH((s + 1) & 1);
+        if (R == 1 && (EPS == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
         if (EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
             e = wave_max_nonneg(lanecore ? e : 0.f);
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
@@ -756,7 +791,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
             seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
         }
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
-        if (s + 1 < g.T) __syncthreads();
+        if (!P2P && s + 1 < g.T) __syncthreads();
 #endif
     }
     if (EPS == 1) {
@@ -777,6 +812,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     }
 #undef HS_ROW
 #undef HS_PUBLISH
+#undef HS_RAISE
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
 
     if (lanecore) {

@@ -303,7 +303,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
             if (threads && threads != NW * 64) continue;
             const int CH = NW * R * (fold ? 2 : 1) - 2 * T;
             if (CH < 1) continue;
-            const int lds = NW * (fold ? 4096 : 8192) + 128; // edge-row exchange + 32 floats for Eps
+            const int lds = NW * (fold ? 4096 : 8192) + (fold ? 128 : 256); // edge-row exchange + 32 floats for Eps (+ sweep counters)
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
