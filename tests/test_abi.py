@@ -84,3 +84,39 @@ def test_no_oracle_in_product_package():
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "hs_oracle" not in text and "libhs_oracle" not in text, fn
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+
+
+def test_header_is_plain_c_and_a_c_host_links(hs, tmp_path):
+    """include/hsflow.h must be usable from C (C99, no C++): a translation unit that takes the address
+    of every declared entry point compiles with -Wall -Werror, links against libhsflow.so and runs the
+    GPU-free calls."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    names = declared_functions()
+    src = tmp_path / "host.c"
+    src.write_text('#include "hsflow.h"\n#include <stdio.h>\n'
+                   "typedef void (*fn)(void);\n"
+                   "static fn table[] = {\n" + "".join("    (fn)%s,\n" % n for n in names) + "};\n"
+                   "int main(void)\n{\n"
+                   "    hsflow_params p;\n    hsflow_info i;\n    hsflow_ctx *c = 0;\n"
+                   "    hsflow_default_params(&p);\n"
+                   "    i.struct_size = sizeof i;\n"
+                   "    if (p.struct_size != sizeof p || p.term_type != (HSFLOW_TERM_ITER | HSFLOW_TERM_EPS)) return 2;\n"
+                   "    if (hsflow_create(&c, 0, 0, 8, 1, 0, 1) != HSFLOW_E_SIZE || c) return 3;\n"
+                   "    if (hsflow_destroy(0) != HSFLOW_OK || hsflow_get_info(0, &i) != HSFLOW_E_ARG) return 4;\n"
+                   '    printf("%d entry points, version %d, %s\\n", (int)(sizeof table / sizeof table[0]), hsflow_version(), hsflow_status_string(HSFLOW_E_NOTERM));\n'
+                   "    return 0;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(hs._lib.LIB_PATH)
+    exe = str(tmp_path / "host")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", exe, "-L", libdir, "-lhsflow",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert ("%d entry points" % len(names)) in r.stdout and "termination criteria never met" in r.stdout
