@@ -27,7 +27,7 @@ constexpr int kMaxFuse = 32;        // upper bound on sweeps per fused launch
 constexpr int kLdsLimit = 160 * 1024; // bytes of LDS per CU on gfx950
 constexpr int kNumCU = 256;
 
-std::string g_create_error;
+thread_local std::string g_create_error; // last error of a call without a context, per host thread
 
 struct FusedPlan {
     hsk::FusedGeom g;

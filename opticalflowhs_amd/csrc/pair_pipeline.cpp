@@ -30,7 +30,7 @@ struct hsflow_pipeline {
 
 namespace {
 
-std::string g_pipeline_create_error;
+thread_local std::string g_pipeline_create_error;
 
 int pfail(hsflow_pipeline *pl, int code, const std::string &msg)
 {
