@@ -40,7 +40,14 @@ def chunks(total, size):
 
 
 class HSFlowSlabBackend(object):
-    """Per-rank solver over the local rows (product implementation: the HIP context)."""
+    """Per-rank solver over the local rows (product implementation: the HIP context).
+
+    stream = None: the context works on a private stream and every hand-over to torch.distributed is
+    bracketed by host synchronisation (simple, used by the thread-based tests).
+    stream = a HIP stream handle that is ALSO torch's current stream (e.g.
+    `torch.cuda.current_stream().cuda_stream` after `torch.cuda.set_stream`): sweeps are only enqueued
+    (`hsflow_solve_async`), the halo copies ride the same stream, and RCCL orders itself against that
+    stream -- the host never waits between chunks, so the GPU runs the chunks back to back."""
 
     def __init__(self, hs, width, local_height, device, stream=None):
         import torch
@@ -48,14 +55,18 @@ class HSFlowSlabBackend(object):
         self.hs = hs
         self.ctx = hs.HSFlow(width, local_height, 1, device=device, stream=stream, own_stream=stream is None)
         self.width, self.height, self.device = width, local_height, device
+        self.enqueue_only = stream is not None
 
     def set_frames(self, prev, curr):
         self.ctx.set_frames(prev, curr)
 
     def sweep(self, n, lam, first):
         # derivatives are computed by the first chunk only; later chunks continue from the flow
-        self.ctx.solve(lam=lam, max_iter=n, term_type=self.hs.TERM_ITER, use_previous=not first,
-                       reuse_derivatives=not first)
+        kw = dict(lam=lam, max_iter=n, term_type=self.hs.TERM_ITER, use_previous=not first, reuse_derivatives=not first)
+        if self.enqueue_only:
+            self.ctx.solve_async(**kw)
+        else:
+            self.ctx.solve(**kw)
 
     def new_rows(self, nrows):
         t = self.torch
@@ -65,12 +76,15 @@ class HSFlowSlabBackend(object):
 
     def get_rows(self, row0, u, v):
         self.ctx.flow_rows_to(u, v, row0, u.shape[0])
-        self.ctx.synchronize()
+        if not self.enqueue_only:
+            self.ctx.synchronize()
 
     def put_rows(self, row0, u, v):
-        self.torch.cuda.synchronize(self.device)  # the received rows were written on torch's stream
+        if not self.enqueue_only:
+            self.torch.cuda.synchronize(self.device)  # the received rows were written on torch's stream
         self.ctx.set_flow_rows_from(u, v, row0, u.shape[0])
-        self.ctx.synchronize()
+        if not self.enqueue_only:
+            self.ctx.synchronize()
 
     def flow(self):
         return self.ctx.flow()

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--halo", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--check", action="store_true", help="compare the owned rows with a whole-frame solve on this rank's GPU")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -44,8 +45,13 @@ def main():
             dist.init_process_group(backend=backend)
     import opticalflowhs_amd as hs
     from opticalflowhs_amd import slab, synth
+    # the context shares torch's current stream: sweeps, halo copies and RCCL are ordered on the device,
+    # the host only enqueues
+    tstream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(tstream)
     s = slab.SlabSolver(dist, rank, world, W, H, args.halo,
-                        lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local), stage_on_host=(backend != "nccl"))
+                        lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, stream=tstream.cuda_stream),
+                        stage_on_host=(backend != "nccl"))
     r0, r1 = s.local_frame_rows()
     A, B = synth.translating_pair(W, H, seed=3, row0=r0, rows=r1 - r0)  # each rank generates only its rows
     s.set_frames(A, B)
@@ -71,6 +77,17 @@ def main():
                           "unit": "Mpix*iter/s", "n_gpus": world, "seconds": t, "width": W, "height": H, "iters": args.iters,
                           "halo_rows": args.halo, "exchanges": n_ex, "bytes_per_exchange_per_boundary": 2 * 2 * args.halo * W * 4,
                           "backend": backend}))
+    if args.check:  # the slab result must be the single-GPU result, bit for bit
+        Af, Bf = synth.translating_pair(W, H, seed=3)
+        with hs.HSFlow(W, H, own_stream=True) as full:
+            full.set_frames(Af, Bf)
+            full.solve(lam=1.0, max_iter=args.iters, term_type=hs.TERM_ITER)
+            uf, vf = full.flow()
+        uo, vo = s.owned_flow()
+        ok = bool(np.array_equal(uo, uf[s.lo:s.hi]) and np.array_equal(vo, vf[s.lo:s.hi]))
+        print("rank %d rows [%d, %d): %s" % (rank, s.lo, s.hi, "identical to the whole-frame solve" if ok else "MISMATCH"), flush=True)
+        if not ok:
+            sys.exit(3)
     s.close()
     if world > 1:
         dist.barrier()
