@@ -190,6 +190,8 @@ def main():
             if tr.get("width") == W and tr.get("height") == H and tr.get("fuse_steps") == info["fuse_steps"]:
                 out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = tr.get("source")
+                if tr.get("hbm_bytes_per_launch"):  # what HBM physically moves per second during a launch
+                    out["roofline"]["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
         except (ValueError, OSError):
             pass
 
