@@ -151,7 +151,7 @@ def main():
         der_ms += pi["deriv_ms"]
         launches += pi["jacobi_launches"]
 
-    KNAME = {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused", hs.KERNEL_STRIP: "strip"}
+    KNAME = {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused", hs.KERNEL_STRIP: "strip", hs.KERNEL_FOLD: "fold"}
     px = W * H * pairs
     ms_per_step = elapsed / args.steps * 1e3
     value = world * px * iters * args.steps / elapsed / 1e6

@@ -71,7 +71,8 @@ extern "C" {
 #define HSFLOW_KERNEL_FUSED 2  /* `fuse_steps` iterations per launch on an LDS tile with halo */
 #define HSFLOW_KERNEL_STRIP 3  /* `fuse_steps` iterations per launch on register-resident strips:
                                   a wavefront holds 256 columns x strip_rows rows in VGPRs, DPP
-                                  for left/right, LDS only for strip-edge rows (AUTO picks this) */
+                                  for left/right, LDS only for strip-edge rows (AUTO picks this, or
+                                  its folded form below ~1.5 Mpixel per context)              */
 #define HSFLOW_KERNEL_FOLD 4   /* as STRIP, two 128-column strips per wavefront (half the LDS
                                   exchange; inner boundary swapped in registers)              */
 
