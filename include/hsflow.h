@@ -161,8 +161,8 @@ int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t 
 /* Derivative pass + Jacobi iterations for every pair of the context.  hsflow_solve returns
  * after the device finished; hsflow_solve_async only enqueues (no profile) and the caller
  * synchronises the stream or calls hsflow_synchronize.  Asynchronous solves take ITER termination
- * with any kernel, or ITER|EPS (the reference's call, OpticalFlowOpenCV.cpp:29) with the strip
- * kernel: the early-stop check is then owed until hsflow_synchronize / hsflow_get_flow /
+ * with any kernel, or ITER|EPS (the reference's call, OpticalFlowOpenCV.cpp:29) with the strip /
+ * fold kernels (what AUTO picks): the early-stop check is then owed until hsflow_synchronize / hsflow_get_flow /
  * hsflow_get_info / the next solve settles it -- if the fast pass cannot prove that the stop
  * never fired, the solve is repeated exactly (hsflow_info.eps_rerun = 1), so flow copied out by
  * an earlier hsflow_get_flow_async has to be fetched again in that case. */
@@ -218,7 +218,7 @@ int hsflow_host_unregister(void *p);
  * run beside the solve of pair i.  It replaces the per-pair body of the reference's run()
  * (HSOpticalFlowOpenCL.cpp:744-767: write frames, derivatives, iterations, read u, v).
  * The host buffers of a submitted pair belong to the pipeline until wait(ticket) returned; use
- * page-locked memory for them.  Termination: ITER, or ITER|EPS (strip kernel) -- whatever
+ * page-locked memory for them.  Termination: ITER, or ITER|EPS (strip / fold kernel) -- whatever
  * hsflow_solve_async accepts; a pair whose early stop fired is re-solved inside wait().
  * Single-owner like a context; one pipeline per (thread, device). */
 typedef struct hsflow_pipeline hsflow_pipeline;

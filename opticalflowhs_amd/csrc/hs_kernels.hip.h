@@ -868,7 +868,7 @@ __device__ __forceinline__ float lane_xor32(float x, bool lower)
     return __uint_as_float(lower ? r[0] : r[1]);
 }
 
-template <int R, int NTMAX, bool EPS>
+template <int R, int NTMAX, int EPS> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
 __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
                                                        const float *__restrict__ u_in,
                                                        const float *__restrict__ v_in,
@@ -876,7 +876,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        float *__restrict__ v_out, const StripGeom g,
                                                        const float ilambda,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
-                                                       unsigned long long *__restrict__ stamps)
+                                                       unsigned long long *__restrict__ stamps,
+                                                       const float eps_thr)
 {
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
         if (rdist[r] <= g.T - 1 - s) {                                                             \
             const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
             strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
-            if (EPS) {                                                                             \
+            if (EPS == 1) {                                                                        \
                 if (((rowcore >> r) & 1u) && lanecore) {                                           \
                     e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
                     if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
@@ -999,6 +1000,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
     // at the region edge the wavefront's own slot stands in (junk the validity argument tolerates)
     const int wo = lower ? (w < NW - 1 ? w + 1 : w) : (w > 0 ? w - 1 : w);
     const int ho = lower ? (w < NW - 1 ? 0 : 1) : (w > 0 ? 1 : 0);
+    int seen_n = 0; // EPS == 2: sweeps in which some lane of this wavefront saw a change >= eps_thr
 #pragma unroll 1
     for (int s = 0; s < g.T; s++) {
         const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
             constexpr int R1 = R > 1 ? 1 : 0;
             HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
         }
-        if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+        if (EPS == 2 || s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
 #pragma unroll
         for (int r = 1; r < R; r++) {
             const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
@@ -1028,7 +1030,14 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
             else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
             puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
         }
-        if (EPS) {
+        if (EPS == 2) {
+            // witness (k_jacobi_strip explains it): old and new value of the published row -- register
+            // row 0 of each half -- at column x0 come back from the two exchange buffers
+            const float nu = *(const float *)(HF_SLOT((s + 1) & 1, w, lower ? 1 : 0) + hl);
+            const float ou = *(const float *)(HF_SLOT(s & 1, w, lower ? 1 : 0) + hl);
+            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
+        }
+        if (EPS == 1) {
             e = wave_max(e);
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
@@ -1039,12 +1048,20 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
         }
         if (s + 1 < g.T) __syncthreads();
     }
-    if (EPS) {
+    if (EPS == 1) {
         __syncthreads();
         if (w == 0) {
             float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
             x = wave_max(x);
             if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+        }
+    }
+    if (EPS == 2) {
+        if (lane == 0) eps_lds[w] = seen_n == g.T ? __builtin_inff() : 0.f;
+        __syncthreads();
+        if (w == 0) {
+            const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
+            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
         }
     }
 #undef HF_ROW

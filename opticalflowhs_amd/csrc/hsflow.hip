@@ -349,7 +349,7 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
                           float *uo, float *vo, float coeff, bool configure_only)
 {
     auto kern = [] {
-        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS != 0>;
+        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS>;
         else return hsk::k_jacobi_strip<R, NTMAX, EPS>;
     }();
     static bool configured[64] = {};
@@ -360,12 +360,8 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
         configured[c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
-    if constexpr (FOLD)
-        hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                           uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr);
-    else
-        hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                           uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
 }
 
@@ -404,8 +400,9 @@ hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *
     if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         StripPlan sp = pl.s;
         sp.g.zero_in = zero_in;
-        if (sp.fold) return eps ? launch_strip_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
-                                : launch_strip_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        if (sp.fold) return eps == 2 ? launch_strip_e<2, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                            : eps  ? launch_strip_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                   : launch_strip_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
         return eps == 2 ? launch_strip_e<2, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
                : eps  ? launch_strip_e<1, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
                       : launch_strip_e<0, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
@@ -787,17 +784,16 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
     // AUTO: the register-strip kernel; below ~1.5 Mpixel per context its folded form (128-column strips:
     // twice the tiles across, so small frames reach more CUs -- measured 5-25 % faster from 160x120 to
-    // 1600x900 at 100 sweeps, tools/crossover.py).  EPS termination stays with the plain strip kernel,
-    // which has the cheap witness launches.
+    // 1600x900 at 100 sweeps, tools/crossover.py).
     const bool small_frame = (long long)c->W * c->H * c->N <= 1500000LL;
-    const int kernel = p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel
-                       : ((small_frame && !use_eps) ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
+    const int kernel = p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel : (small_frame ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
     if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP &&
         kernel != HSFLOW_KERNEL_FOLD)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
     const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
-    if (async && use_eps && !(use_iter && p.max_iter > 0 && p.max_iter <= (1 << 16) && kernel == HSFLOW_KERNEL_STRIP && !c->force_exact))
-        return fail(c, HSFLOW_E_ARG, "solve_async with EPS termination needs ITER|EPS with a sweep budget and the strip kernel "
+    if (async && use_eps && !(use_iter && p.max_iter > 0 && p.max_iter <= (1 << 16) &&
+                              (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact))
+        return fail(c, HSFLOW_E_ARG, "solve_async with EPS termination needs ITER|EPS with a sweep budget and the strip / fold kernel "
                                      "(ITER-only termination works with every kernel)");
     // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
     // EPS-only runs use chunks until Eps < epsilon.
@@ -886,7 +882,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     if (use_iter && p.max_iter > 0 && budget <= kSpecMax) {
         const int iters = (int)budget;
         const size_t px = (size_t)c->plane * c->N;
-        const bool witness = kernel == HSFLOW_KERNEL_STRIP && !c->force_exact;
+        const bool witness = (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact;
         const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
         if (p.use_previous) { // the starting flow is kept: the ping-pong buffers get overwritten
             if (!c->dUb) HS_HIP(c, hipMalloc((void **)&c->dUb, px * sizeof(float)));
