@@ -446,6 +446,20 @@ hipError_t launch_deriv(const hsflow_ctx *c)
     return hipGetLastError();
 }
 
+// The graph cache is keyed by everything a captured launch sequence depends on (sizes, kernel shape,
+// lambda, epsilon ...); a caller that varies those from call to call must not grow it without bound.
+constexpr size_t kMaxGraphs = 32;
+void trim_graph_cache(hsflow_ctx *c)
+{
+    if (c->graphs.size() < kMaxGraphs) return;
+    hipStreamSynchronize(c->stream); // no replay of an old graph may still be running
+    for (auto &kv : c->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    c->graphs.clear();
+}
+
 int check_ctx(hsflow_ctx *c, int pair)
 {
     if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
@@ -852,6 +866,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                 ge.cur_after = c->cur;
                 ge.launches = c->info.jacobi_launches;
                 HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+                trim_graph_cache(c);
                 it = c->graphs.emplace(key, ge).first;
             }
             HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
@@ -970,7 +985,8 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
                     ge.cur_after = c->cur;
                     ge.launches = launches;
                     HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
-                    it = c->graphs.emplace(key, ge).first;
+                    trim_graph_cache(c);
+                it = c->graphs.emplace(key, ge).first;
                 }
                 HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
                 c->cur = it->second.cur_after;

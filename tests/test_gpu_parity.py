@@ -459,3 +459,19 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
         assert stop["jacobi_launches"] > plain["jacobi_launches"]          # witness pass + exact pass + re-run
         if stop["iterations_done"] == n3:
             check("iter_eps_early_stop", (u3, v3), (uo3, vo3))
+
+
+def test_graph_cache_stays_bounded(hs, oracle, gpu_ok):
+    """A caller that changes lambda on every call creates a new captured sequence each time; the cache is
+    trimmed instead of growing without bound, and results stay right across the trim."""
+    W, H = 96, 64
+    A, B = synth.translating_pair(W, H, seed=11)
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        for i in range(70):
+            lam = 0.5 + 0.01 * i
+            ctx.solve(lam=lam, max_iter=6, term_type=ITER, use_graph=True)
+            if i % 23 == 0 or i == 69:
+                u, v = ctx.flow()
+                uo, vo = oracle.calc_optical_flow_hs(A, B, lam, 6, term_type=ITER)
+                check("graph_trim_%d" % i, (u, v), (uo, vo))
