@@ -1326,6 +1326,7 @@ int hsflow_set_frames_u8(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     HS_HIP(c, hipStreamSynchronize(c->stream));
@@ -1349,6 +1350,7 @@ int hsflow_set_frames_u8_async(hsflow_ctx *c, int pair, const uint8_t *prev, siz
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     HS_HIP(c, copy_rows_async(c, c->dA + pair * c->plane, c->P, prev, ps, c->W, c->H, hipMemcpyHostToDevice));
@@ -1362,6 +1364,7 @@ int hsflow_set_frames_u8_device(hsflow_ctx *c, int pair, const void *dprev, size
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!dprev || !dcurr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     if ((st = copy_frame_in(c, c->dA + pair * c->plane, dprev, ps, hipMemcpyDeviceToDevice, false))) return st;
@@ -1375,6 +1378,7 @@ int hsflow_push_frame_u8(hsflow_ctx *c, int pair, const uint8_t *next, size_t ns
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!next) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ns < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "push_frame needs a previous pair");
@@ -1415,6 +1419,7 @@ int hsflow_set_frames_bgr8(hsflow_ctx *c, int pair, const uint8_t *prev, size_t 
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ps < (size_t)c->W * 3 || cs < (size_t)c->W * 3) return fail(c, HSFLOW_E_SIZE, "colour frame stride smaller than 3*width");
     if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, true, blur3x3 != 0))) return st;
@@ -1428,6 +1433,7 @@ int hsflow_set_frames_gray8_blur(hsflow_ctx *c, int pair, const uint8_t *prev, s
 {
     int st = check_ctx(c, pair);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
     if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, false, true))) return st;
@@ -1501,6 +1507,7 @@ int hsflow_set_flow_device(hsflow_ctx *c, int pair, int row0, int nrows, const v
 {
     int st = flow_rows_args(c, pair, row0, nrows, du, us, dv, vs);
     if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
     const size_t rowb = (size_t)c->W * 4;
     const long long off = pair * c->plane + (long long)row0 * c->P;
     HS_HIP(c, hipMemcpy2DAsync(c->dU[c->cur] + off, (size_t)c->P * 4, du, us, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));

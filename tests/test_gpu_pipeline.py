@@ -132,6 +132,15 @@ def test_pipeline_iter_eps_like_the_reference_call(hs, oracle, gpu_ok):
         u, v = ctx.flow()                               # settles the owed check, then copies
         i2 = ctx.info()
         assert i2["iterations_done"] == 1 and i2["eps_rerun"] == 1 and not u.any() and not v.any()
+        # new frames before the owed check was settled: the pending solve is settled first, on ITS frames
+        ctx.set_frames(*pairs[2])
+        ctx.solve_async(lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+        ctx.set_frames(*pairs[1])
+        i3 = ctx.info()
+        u, v = ctx.flow()
+        assert i3["iterations_done"] == 1 and i3["eps_rerun"] == 1 and not u.any() and not v.any()
+        ctx.solve(lam=0.3, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+        assert np.array_equal(ctx.flow()[0], ref[1][0][0])
     assert ref[2][1] == 1 and all(r[1] == it for k, r in enumerate(ref) if k != 2)
     with hs.PairPipeline(W, H, depth=3) as pl:
         outs = []
