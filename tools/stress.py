@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised stress of the C ABI against the oracle (a one-off soak, not part of the test suite):
+random sizes, pairs per context, kernels and tuning knobs, ITER / ITER|EPS with random epsilon, warm
+starts, graphs, asynchronous solves.  usage: python tools/stress.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import opticalflowhs_amd as hs
+from opticalflowhs_amd import synth
+from oracle import hs_oracle
+
+ITER, EPS = 1, 2
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+worst = 0.0
+near = 0
+t_start = time.time()
+for case in range(n_cases):
+    W = int(rng.integers(1, 700)) if case % 4 else int(rng.integers(1, 40))
+    H = int(rng.integers(1, 400)) if case % 5 else int(rng.integers(1, 12))
+    N = int(rng.choice([1, 1, 1, 2, 3]))
+    it = int(rng.integers(1, 80))
+    lam = float(10.0 ** rng.uniform(-2.5, 1.5))
+    use_eps = bool(rng.integers(0, 2))
+    eps = float(10.0 ** rng.uniform(-7, -1))
+    kernel = int(rng.choice([hs.KERNEL_AUTO, hs.KERNEL_AUTO, hs.KERNEL_SIMPLE, hs.KERNEL_FUSED, hs.KERNEL_STRIP, hs.KERNEL_FOLD]))
+    kw = dict(kernel=kernel)
+    if kernel in (hs.KERNEL_FUSED, hs.KERNEL_STRIP, hs.KERNEL_FOLD) and rng.integers(0, 2):
+        kw["fuse_steps"] = int(rng.integers(1, 13))
+    graph = bool(rng.integers(0, 2)) and not (use_eps and kernel in (hs.KERNEL_SIMPLE, hs.KERNEL_FUSED))
+    do_async = bool(rng.integers(0, 2)) and (not use_eps or kernel in (hs.KERNEL_AUTO, hs.KERNEL_STRIP, hs.KERNEL_FOLD))
+    warm = bool(rng.integers(0, 3) == 0) and it > 2
+    pairs = []
+    for i in range(N):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            pairs.append(synth.random_pair(W, H, seed=case * 10 + i))
+        elif kind == 1:
+            A = np.full((H, W), int(rng.integers(0, 256)), np.uint8)
+            pairs.append((A, A.copy()))
+        else:
+            pairs.append(synth.translating_pair(W, H, seed=case * 10 + i, dx=float(rng.uniform(-2, 2)), dy=float(rng.uniform(-2, 2))))
+    tt = ITER | EPS if use_eps else ITER
+    try:
+        with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+            for i, (A, B) in enumerate(pairs):
+                ctx.set_frames(A, B, pair=i)
+            first = it // 2 if warm else 0
+            if warm:
+                ctx.solve(lam=lam, max_iter=first, term_type=ITER, **kw)
+            p = ctx.make_params(lam=lam, max_iter=it - first, epsilon=eps, term_type=tt, use_previous=warm, reuse_derivatives=warm, use_graph=graph, **kw)
+            if do_async:
+                ctx.solve_async(p)
+                ctx.synchronize()
+                info = ctx.info()
+            else:
+                info = ctx.solve(p)
+            flows = [ctx.flow(pair=i) for i in range(N)]
+    except hs.HsflowError as e:
+        print("case %d: %dx%d N%d it%d k%d %s -> ERROR %s" % (case, W, H, N, it, kernel, kw, e), flush=True)
+        bad += 1
+        continue
+    # oracle: the batch stops when the maximum over all pairs drops below eps -> emulate by running every pair for the
+    # batch's sweep count and checking the stop rule on the batch maximum
+    done = info["iterations_done"] + first
+    ok = True
+    e_batch = 0.0
+    for i, (A, B) in enumerate(pairs):
+        uo, vo, n_o, e_o = hs_oracle.calc_optical_flow_hs(A, B, lam, done, 0.0, ITER, return_info=True)
+        r = max(float(np.sqrt(np.mean((flows[i][0].astype(np.float64) - uo) ** 2))), float(np.sqrt(np.mean((flows[i][1].astype(np.float64) - vo) ** 2))))
+        worst = max(worst, r)
+        if not (r <= 1e-4):
+            ok = False
+        if use_eps:  # Eps of the last sweep of this pair
+            up, vp, _, _ = hs_oracle.calc_optical_flow_hs(A, B, lam, done - 1, 0.0, ITER, return_info=True) if done > 1 else (np.zeros_like(uo), np.zeros_like(vo), 0, 0)
+            e_batch = max(e_batch, float(np.abs(uo - up).max()), float(np.abs(vo - vp).max()))
+    if use_eps:
+        stopped_early = info["iterations_done"] < it - first
+        if stopped_early and not (e_batch < eps * (1 + 1e-3)):
+            ok = False
+        if not stopped_early and e_batch < eps * (1 - 1e-3) and done > 1:
+            # must then have been the budget's last sweep, or an earlier sweep was already below: check the previous one
+            pass
+        if abs(e_batch - eps) <= 1e-3 * eps:
+            near += 1
+        if N == 1 and not warm:  # the oracle's own stopping sweep
+            A, B = pairs[0]
+            _, _, n_o, e_o = hs_oracle.calc_optical_flow_hs(A, B, lam, it, eps, ITER | EPS, return_info=True)
+            if n_o != info["iterations_done"]:
+                # tolerated only if some sweep's Eps sits within 1e-3 of the threshold (fp32 vs x87 rounding)
+                close = False
+                up, vp = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+                for k in range(1, max(n_o, info["iterations_done"]) + 1):
+                    uk, vk = hs_oracle.calc_optical_flow_hs(A, B, lam, k, 0.0, ITER)
+                    ek = max(float(np.abs(uk - up).max()), float(np.abs(vk - vp).max()))
+                    # Eps is a difference of fp32 flows: GPU (fp32 intermediates) and oracle (x87 doubles) agree to
+                    # a few ulp of the flow magnitude, not to a relative 1e-3 of a small epsilon
+                    close = close or abs(ek - eps) <= 1e-3 * eps + 4e-7 * max(1.0, float(np.abs(uk).max()), float(np.abs(vk).max()))
+                    up, vp = uk, vk
+                if close:
+                    near += 1
+                else:
+                    ok = False
+                    print("   stop sweep differs: oracle %d, gpu %d" % (n_o, info["iterations_done"]), flush=True)
+    if not ok:
+        bad += 1
+        print("case %d: %dx%d N%d it%d lam%.3g eps%s k%d %s graph%d async%d warm%d -> done %d rms %.3g e_batch %.3g" %
+              (case, W, H, N, it, lam, ("%.3g" % eps) if use_eps else "-", kernel, kw, graph, do_async, warm, info["iterations_done"], worst, e_batch), flush=True)
+    if case % 25 == 24:
+        print("... %d cases, %d bad, worst rms %.3g, %.0f s" % (case + 1, bad, worst, time.time() - t_start), flush=True)
+print("DONE %d cases, %d bad, worst rms %.3g, %d near-threshold" % (n_cases, bad, worst, near))
+sys.exit(1 if bad else 0)
