@@ -43,6 +43,23 @@ for case in range(n_cases):
         else:
             pairs.append(synth.translating_pair(W, H, seed=case * 10 + i, dx=float(rng.uniform(-2, 2)), dy=float(rng.uniform(-2, 2))))
     tt = ITER | EPS if use_eps else ITER
+    if case % 6 == 5:  # the classic ("-cl") mode: bit-exact against its oracle, both kernels, as shipped or not
+        alpha = float(rng.uniform(0.3, 25.0))
+        shipped = bool(rng.integers(0, 2))
+        ckw = dict(kernel=int(rng.choice([hs.KERNEL_AUTO, hs.KERNEL_SIMPLE, hs.KERNEL_FUSED])))
+        if ckw["kernel"] != hs.KERNEL_SIMPLE and rng.integers(0, 2):
+            ckw["fuse_steps"] = int(rng.integers(1, 10))
+        with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+            for i, (A, B) in enumerate(pairs):
+                ctx.set_frames(A, B, pair=i)
+            ctx.solve(mode=hs.MODE_CLASSIC_AS_SHIPPED if shipped else hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, **ckw)
+            for i, (A, B) in enumerate(pairs):
+                u, v = ctx.flow(pair=i)
+                uo, vo = hs_oracle.classic_flow(A, B, alpha, it, update_v=not shipped)
+                if not (np.array_equal(u, uo) and np.array_equal(v, vo)):
+                    bad += 1
+                    print("case %d: classic %dx%d N%d it%d alpha%.3g shipped%d %s pair %d MISMATCH" % (case, W, H, N, it, alpha, shipped, ckw, i), flush=True)
+        continue
     try:
         with hs.HSFlow(W, H, N, own_stream=True) as ctx:
             for i, (A, B) in enumerate(pairs):
