@@ -120,3 +120,28 @@ def test_header_is_plain_c_and_a_c_host_links(hs, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert ("%d entry points" % len(names)) in r.stdout and "termination criteria never met" in r.stdout
+
+
+def test_package_fails_loudly_without_the_hip_library(tmp_path):
+    """No CPU fallback: importing the package when libhsflow.so is absent must raise, and nothing under
+    opticalflowhs_amd/ may import or mention the oracle."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "os.environ['HSFLOW_LIB_PATH'] = %r\n"
+            "sys.path.insert(0, %r)\n"
+            "try:\n"
+            "    import opticalflowhs_amd\n"
+            "except ImportError as e:\n"
+            "    print('IMPORT-ERROR', e)\n"
+            "else:\n"
+            "    print('IMPORTED')\n") % (str(tmp_path / "no_such_libhsflow.so"), ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "IMPORT-ERROR" in r.stdout and "no CPU fallback" in r.stdout.replace("There is no", "no"), (r.stdout, r.stderr[-500:])
+    pkg = os.path.join(ROOT, "opticalflowhs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+                assert "hs_oracle" not in text and "libhs_oracle" not in text, os.path.join(dirpath, f)
