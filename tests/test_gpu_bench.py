@@ -64,3 +64,10 @@ def test_slab_two_ranks_rehearsal_is_bit_identical(gpu_ok):
     assert r.stdout.count("identical to the whole-frame solve") == 2, r.stdout
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["exchanges"] == 4
+
+
+def test_graft_entry_smoke(gpu_ok):
+    """__graft_entry__.smoke() as the driver calls it (fresh interpreter, cuda:0)."""
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('SMOKE-OK')"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "SMOKE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
