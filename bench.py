@@ -183,17 +183,19 @@ def main():
         "kernel_ms_per_step": {"deriv": der_ms / nprof, "jacobi": jac_ms / nprof, "launches": launches / nprof},
     }
 
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(traffic_file):
+    # HBM bytes per launch from the committed PMC summaries (tools/collect_profiles.py): whichever one was
+    # taken on this workload with this launch depth
+    import glob
+    for traffic_file in [os.path.join(ROOT, "profiles", "traffic_latest.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             tr = json.load(open(traffic_file))
-            if tr.get("width") == W and tr.get("height") == H and tr.get("fuse_steps") == info["fuse_steps"]:
-                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = tr.get("source")
-                if tr.get("hbm_bytes_per_launch"):  # what HBM physically moves per second during a launch
-                    out["roofline"]["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
         except (ValueError, OSError):
-            pass
+            continue
+        if tr.get("width") == W and tr.get("height") == H and tr.get("fuse_steps") == info["fuse_steps"] and tr.get("hbm_bytes_per_launch"):
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr.get("source")
+            out["roofline"]["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9  # what HBM physically moves
+            break
 
     if rank == 0 and world == 1 and not args.skip_cpu:
         from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port

@@ -54,7 +54,8 @@ def main():
                         "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0})
     with open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1)
-    if "hbm_bytes_per_launch" in out:
+    # traffic_latest.json follows the default bench workload only; bench.py also searches every *_traffic.json
+    if "hbm_bytes_per_launch" in out and out.get("width") == 1920 and out.get("height") == 1080:
         shutil.copy(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), os.path.join(ROOT, "profiles", "traffic_latest.json"))
     print(json.dumps(out, indent=1))
     if stats:
