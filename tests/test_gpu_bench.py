@@ -35,6 +35,7 @@ def test_bench_single_gpu_line(gpu_ok):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["traffic"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"]  # the committed PMC summary of this workload
     assert abs(d["value"] - 1920 * 1080 * 100 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mpix*iter/s"
