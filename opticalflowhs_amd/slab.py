@@ -49,13 +49,35 @@ class HSFlowSlabBackend(object):
     (`hsflow_solve_async`), the halo copies ride the same stream, and RCCL orders itself against that
     stream -- the host never waits between chunks, so the GPU runs the chunks back to back."""
 
-    def __init__(self, hs, width, local_height, device, stream=None):
+    def __init__(self, hs, width, local_height, device, stream=None, torch_stream=None):
         import torch
         self.torch = torch
         self.hs = hs
+        # torch_stream: a torch.cuda.Stream the context shares; `activate()` then makes it torch's current
+        # stream, so that several backends of one rank (OverlappedSlabSolver) each order their own work
+        self.tstream = torch_stream
+        if torch_stream is not None:
+            stream = torch_stream.cuda_stream
         self.ctx = hs.HSFlow(width, local_height, 1, device=device, stream=stream, own_stream=stream is None)
         self.width, self.height, self.device = width, local_height, device
         self.enqueue_only = stream is not None
+
+    def activate(self):
+        """Context manager under which this backend's calls and the P2P calls for it must be made."""
+        import contextlib
+        return self.torch.cuda.stream(self.tstream) if self.tstream is not None else contextlib.nullcontext()
+
+    def record(self):
+        """A marker after everything enqueued so far (None when every call is synchronous anyway)."""
+        if self.tstream is None:
+            return None
+        ev = self.torch.cuda.Event()
+        ev.record(self.tstream)
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None and self.tstream is not None:
+            self.tstream.wait_event(ev)
 
     def set_frames(self, prev, curr):
         self.ctx.set_frames(prev, curr)
@@ -185,6 +207,139 @@ class SlabSolver(object):
 
     def close(self):
         self.backend.close()
+
+
+class OverlappedSlabSolver(object):
+    """Two sub-slabs per rank, worked alternately, so that the halo exchange with the neighbouring RANK
+    runs under the sweeps of the other sub-slab ("overlapped with interior-row compute").
+
+    Rank r owns the virtual slabs 2r (A, upper) and 2r+1 (B, lower) of a 2*world partition.  Per chunk:
+        sweep(A); post A's top rows <-> rank r-1      (in flight while B is being swept)
+        sweep(B); post B's bottom rows <-> rank r+1   (in flight while A's next chunk is swept)
+        A's bottom rows <-> B's top rows locally (device copies ordered by stream events)
+    and the rows received from a neighbouring rank are written into the halo right before that sub-slab's
+    next sweep.  Same arithmetic as SlabSolver with 2*world ranks: bit-identical to the whole-frame solve.
+    Backends need the interface of HSFlowSlabBackend incl. activate() / record() / wait_event()."""
+
+    def __init__(self, dist, rank, world, width, height, halo, make_backend, stage_on_host=False):
+        if halo < 1:
+            raise ValueError("halo must be >= 1")
+        vworld = 2 * world
+        if height // vworld < halo:
+            raise ValueError("sub-slabs of %d rows are thinner than the halo (%d)" % (height // vworld, halo))
+        self.dist, self.rank, self.world = dist, rank, world
+        self.width, self.height, self.halo = width, height, halo
+        self.stage_on_host = stage_on_host
+        self.subs = []
+        for j in range(2):
+            lo, hi, top, bot = slab_extent(height, vworld, 2 * rank + j, halo)
+            sub = dict(lo=lo, hi=hi, top=top, bot=bot, row0=lo - top, local_height=(hi + bot) - (lo - top))
+            sub["backend"] = make_backend(width, sub["local_height"])
+            sub["pending"] = None   # (work handles, wire buffers, device buffers, halo row) of a posted exchange
+            sub["bufs"] = None
+            self.subs.append(sub)
+        self.lo, self.hi = self.subs[0]["lo"], self.subs[1]["hi"]
+
+    def local_frame_rows(self):
+        """Frame rows [row0, row1) this rank must provide (both sub-slabs with their halos)."""
+        return self.subs[0]["row0"], self.subs[1]["row0"] + self.subs[1]["local_height"]
+
+    def set_frames(self, prev_local, curr_local):
+        r0, r1 = self.local_frame_rows()
+        if prev_local.shape != (r1 - r0, self.width):
+            raise ValueError("local frames must have shape (%d, %d)" % (r1 - r0, self.width))
+        for sub in self.subs:
+            a = sub["row0"] - r0
+            sub["backend"].set_frames(prev_local[a:a + sub["local_height"]], curr_local[a:a + sub["local_height"]])
+
+    def _bufs(self, sub):
+        if sub["bufs"] is None:
+            sub["bufs"] = {k: sub["backend"].new_rows(self.halo) for k in ("send", "recv", "local")}
+        return sub["bufs"]
+
+    def _post_remote(self, sub, peer, own_row, halo_row):
+        """Owned rows [own_row, own_row+halo) go to `peer`, its rows come back for the halo at halo_row."""
+        d, b = self.dist, sub["backend"]
+        bufs = self._bufs(sub)
+        b.get_rows(own_row, *bufs["send"])
+        if self.stage_on_host:
+            send = (bufs["send"][0].cpu(), bufs["send"][1].cpu())
+            recv = (bufs["recv"][0].cpu(), bufs["recv"][1].cpu())
+        else:
+            send, recv = bufs["send"], bufs["recv"]
+        ops = [d.P2POp(d.isend, send[0], peer), d.P2POp(d.isend, send[1], peer),
+               d.P2POp(d.irecv, recv[0], peer), d.P2POp(d.irecv, recv[1], peer)]
+        sub["pending"] = (d.batch_isend_irecv(ops), (send, recv), halo_row)
+
+    def _finish_remote(self, sub):
+        if sub["pending"] is None:
+            return
+        works, (send, recv), halo_row = sub["pending"]
+        sub["pending"] = None
+        for w in works:
+            w.wait()
+        bufs = self._bufs(sub)
+        if self.stage_on_host:
+            bufs["recv"][0].copy_(recv[0])
+            bufs["recv"][1].copy_(recv[1])
+        sub["backend"].put_rows(halo_row, *bufs["recv"])
+
+    def _local_exchange(self):
+        """A's last owned rows -> B's top halo, B's first owned rows -> A's bottom halo."""
+        A, B = self.subs
+        h = self.halo
+        ba, bb = A["backend"], B["backend"]
+        with ba.activate():
+            ba.get_rows(A["top"] + (A["hi"] - A["lo"]) - h, *self._bufs(A)["local"])
+            ea = ba.record()
+        with bb.activate():
+            bb.get_rows(B["top"], *self._bufs(B)["local"])
+            eb = bb.record()
+            bb.wait_event(ea)
+            bb.put_rows(0, *self._bufs(A)["local"])                       # rows [B.lo - halo, B.lo)
+            eb2 = bb.record()
+        with ba.activate():
+            ba.wait_event(eb)
+            ba.put_rows(A["top"] + (A["hi"] - A["lo"]), *self._bufs(B)["local"])  # rows [A.hi, A.hi + halo)
+            ba.wait_event(eb2)   # A's buffer is free again only once B has read it
+            ea2 = ba.record()
+        with bb.activate():
+            bb.wait_event(ea2)
+
+    def solve(self, lam, iters):
+        """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchange rounds."""
+        A, B = self.subs
+        plan = chunks(iters, self.halo)
+        n_ex = 0
+        for i, n in enumerate(plan):
+            last = i + 1 == len(plan)
+            with A["backend"].activate():
+                self._finish_remote(A)
+                A["backend"].sweep(n, lam, first=(i == 0))
+                if not last and self.rank > 0:
+                    self._post_remote(A, self.rank - 1, A["top"], 0)
+            with B["backend"].activate():
+                self._finish_remote(B)
+                B["backend"].sweep(n, lam, first=(i == 0))
+                if not last and self.rank + 1 < self.world:
+                    self._post_remote(B, self.rank + 1, B["top"] + (B["hi"] - B["lo"]) - self.halo, B["top"] + (B["hi"] - B["lo"]))
+            if not last:
+                self._local_exchange()
+                n_ex += 1
+        return n_ex
+
+    def owned_flow(self):
+        """(u, v) of the rows this rank owns, as host arrays of shape (hi - lo, width)."""
+        parts = []
+        for sub in self.subs:
+            u, v = sub["backend"].flow()
+            u, v = np.asarray(u), np.asarray(v)
+            parts.append((u[sub["top"]:sub["top"] + (sub["hi"] - sub["lo"])], v[sub["top"]:sub["top"] + (sub["hi"] - sub["lo"])]))
+        return np.concatenate([parts[0][0], parts[1][0]]), np.concatenate([parts[0][1], parts[1][1]])
+
+    def close(self):
+        for sub in self.subs:
+            sub["backend"].close()
 
 
 def shard_pairs(n_pairs, world, rank):

@@ -3,7 +3,7 @@
 The slab driver (opticalflowhs_amd/slab.py) is exercised with a backend that wraps the CPU oracle
 (test infrastructure): what is under test here is the partitioning and the halo exchange, i.e.
 that chunked sweeps + row swaps reproduce the single-domain solve bit for bit.
-usage: python -m torch.distributed.run --nproc-per-node N tests/dist_worker.py W H HALO ITERS OUT
+usage: python -m torch.distributed.run --nproc-per-node N tests/dist_worker.py W H HALO ITERS OUT [overlap]
 """
 import os
 import sys
@@ -48,13 +48,26 @@ class OracleSlabBackend(object):
     def close(self):
         pass
 
+    # everything above is synchronous: the ordering hooks of the overlapped driver are no-ops
+    def activate(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def record(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
 
 def main():
     W, H, halo, iters = (int(x) for x in sys.argv[1:5])
     out = sys.argv[5]
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    s = slab.SlabSolver(dist, rank, world, W, H, halo, OracleSlabBackend)
+    overlapped = len(sys.argv) > 6 and sys.argv[6] == "overlap"
+    cls = slab.OverlappedSlabSolver if overlapped else slab.SlabSolver
+    s = cls(dist, rank, world, W, H, halo, OracleSlabBackend)
     r0, r1 = s.local_frame_rows()
     A, B = synth.translating_pair(W, H, seed=3, row0=r0, rows=r1 - r0)  # each rank makes only its rows
     s.set_frames(A, B)

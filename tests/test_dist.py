@@ -33,13 +33,16 @@ def test_slab_partition_arithmetic():
         slab.SlabSolver(None, 0, 4, 32, 20, 8, lambda w, h: None)  # 5-row slabs, halo 8
 
 
-@pytest.mark.parametrize("world,halo,iters", [(2, 4, 10), (2, 8, 8), (3, 5, 23)])
-def test_slab_exchange_matches_single_domain(tmp_path, oracle, world, halo, iters):
+@pytest.mark.parametrize("world,halo,iters,mode", [(2, 4, 10, "plain"), (2, 8, 8, "plain"), (3, 5, 23, "plain"),
+                                                   (2, 4, 13, "overlap"), (3, 5, 23, "overlap"), (1, 6, 20, "overlap")])
+def test_slab_exchange_matches_single_domain(tmp_path, oracle, world, halo, iters, mode):
+    """mode "overlap": two sub-slabs per rank worked alternately (OverlappedSlabSolver)."""
     W, H = 96, 61
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world * 10 + halo),
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(W), str(H), str(halo), str(iters), str(tmp_path)]
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world * 10 + halo + (100 if mode == "overlap" else 0)),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(W), str(H), str(halo), str(iters), str(tmp_path)] + \
+          (["overlap"] if mode == "overlap" else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     A, B = synth.translating_pair(W, H, seed=3)

@@ -52,14 +52,15 @@ def test_bench_two_ranks_rehearsal(gpu_ok):
     assert abs(d["value"] - 2 * 1920 * 1080 * 100 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
 
 
-def test_slab_two_ranks_rehearsal_is_bit_identical(gpu_ok):
+@pytest.mark.parametrize("extra", [[], ["--overlap"]])
+def test_slab_two_ranks_rehearsal_is_bit_identical(gpu_ok, extra):
     """tools/bench_slab.py with two ranks sharing the card (gloo, halo rows staged through the host): the
     enqueue-only driver (context on torch's stream, no host waits between chunks) must give the whole-frame
     result bit for bit on the rows each rank owns."""
     env = dict(os.environ, HSFLOW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29519", os.path.join(ROOT, "tools", "bench_slab.py"), "--width", "1500", "--height", "700",
-                        "--iters", "53", "--halo", "12", "--steps", "1", "--check"],
+                        "--iters", "53", "--halo", "12", "--steps", "1", "--check"] + extra,
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert r.stdout.count("identical to the whole-frame solve") == 2, r.stdout

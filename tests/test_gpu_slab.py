@@ -56,8 +56,10 @@ class LocalDist(object):
         return out
 
 
-@pytest.mark.parametrize("world,halo,iters,shape", [(2, 8, 30, (300, 512)), (3, 12, 40, (203, 700))])
-def test_slab_matches_single_gpu_bit_for_bit(hs, gpu_ok, world, halo, iters, shape):
+@pytest.mark.parametrize("world,halo,iters,shape,overlapped", [(2, 8, 30, (300, 512), False), (3, 12, 40, (203, 700), False),
+                                                               (2, 8, 30, (300, 512), True), (3, 10, 47, (260, 700), True),
+                                                               (1, 9, 40, (150, 333), True)])
+def test_slab_matches_single_gpu_bit_for_bit(hs, gpu_ok, world, halo, iters, shape, overlapped):
     H, W = shape
     A, B = synth.translating_pair(W, H, seed=3)
     with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
@@ -69,8 +71,13 @@ def test_slab_matches_single_gpu_bit_for_bit(hs, gpu_ok, world, halo, iters, sha
 
     def run(rank):
         try:
-            s = slab.SlabSolver(LocalDist(rank), rank, world, W, H, halo,
-                                lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0))
+            if overlapped:  # two sub-slabs per rank, each context on its own torch stream, calls only enqueued
+                import torch
+                s = slab.OverlappedSlabSolver(LocalDist(rank), rank, world, W, H, halo,
+                                              lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0, torch_stream=torch.cuda.Stream()))
+            else:
+                s = slab.SlabSolver(LocalDist(rank), rank, world, W, H, halo,
+                                    lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0))
             r0, r1 = s.local_frame_rows()
             s.set_frames(A[r0:r1], B[r0:r1])
             s.solve(0.7, iters)

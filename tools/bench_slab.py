@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--halo", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--overlap", action="store_true", help="two sub-slabs per rank: the exchange of one runs under the sweeps of the other")
     ap.add_argument("--check", action="store_true", help="compare the owned rows with a whole-frame solve on this rank's GPU")
     args = ap.parse_args()
     import numpy as np
@@ -45,13 +46,20 @@ def main():
             dist.init_process_group(backend=backend)
     import opticalflowhs_amd as hs
     from opticalflowhs_amd import slab, synth
-    # the context shares torch's current stream: sweeps, halo copies and RCCL are ordered on the device,
-    # the host only enqueues
-    tstream = torch.cuda.Stream(device=local)
-    torch.cuda.set_stream(tstream)
-    s = slab.SlabSolver(dist, rank, world, W, H, args.halo,
-                        lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, stream=tstream.cuda_stream),
-                        stage_on_host=(backend != "nccl"))
+    if args.overlap:
+        # two sub-slabs per rank, each context on its own torch stream: the RCCL exchange of one sub-slab is
+        # in flight while the other one is swept
+        s = slab.OverlappedSlabSolver(dist, rank, world, W, H, args.halo,
+                                      lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, torch_stream=torch.cuda.Stream(device=local)),
+                                      stage_on_host=(backend != "nccl"))
+    else:
+        # the context shares torch's current stream: sweeps, halo copies and RCCL are ordered on the device,
+        # the host only enqueues
+        tstream = torch.cuda.Stream(device=local)
+        torch.cuda.set_stream(tstream)
+        s = slab.SlabSolver(dist, rank, world, W, H, args.halo,
+                            lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, stream=tstream.cuda_stream),
+                            stage_on_host=(backend != "nccl"))
     r0, r1 = s.local_frame_rows()
     A, B = synth.translating_pair(W, H, seed=3, row0=r0, rows=r1 - r0)  # each rank generates only its rows
     s.set_frames(A, B)
@@ -75,7 +83,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "Mpixel*iterations/sec, one frame in row slabs", "value": W * H * args.iters / t / 1e6,
                           "unit": "Mpix*iter/s", "n_gpus": world, "seconds": t, "width": W, "height": H, "iters": args.iters,
-                          "halo_rows": args.halo, "exchanges": n_ex, "bytes_per_exchange_per_boundary": 2 * 2 * args.halo * W * 4,
+                          "halo_rows": args.halo, "overlapped": bool(args.overlap), "exchanges": n_ex, "bytes_per_exchange_per_boundary": 2 * 2 * args.halo * W * 4,
                           "backend": backend}))
     if args.check:  # the slab result must be the single-GPU result, bit for bit
         Af, Bf = synth.translating_pair(W, H, seed=3)
