@@ -687,7 +687,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0); /* one row at a time keeps the VGPR pressure down */    \
+        /* (no scheduling barrier between rows: letting the scheduler overlap them is 1.7 % faster    \
+           and, with this compiler, also spills less in the Eps variants) */                      \
     } while (0)
 #endif
 #if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS) /* diagnostic builds only: wrong results */
