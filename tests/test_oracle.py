@@ -186,3 +186,24 @@ def test_classic_oracle_basics(oracle):
     assert np.isfinite(u).all() and np.abs(v).max() > 0  # the v update is restored
     u0, v0 = oracle.classic_flow(A, A, 15.0, 5)
     assert not u0.any() and not v0.any()
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """Every entry point of the C oracle on small and degenerate sizes with exact-size heap buffers,
+    built with AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_san")
+    srcs = [os.path.join(root, "tests", "oracle_sanitize_main.c")] + \
+           [os.path.join(root, "oracle", f) for f in ("hs_cv_oracle.c", "hs_classic_oracle.c", "hs_preproc_oracle.c")]
+    r = subprocess.run([gcc, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off", "-fopenmp",
+                        "-o", exe] + srcs + ["-lm"], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="3"))
+    assert r.returncode == 0 and "SANITIZED-OK" in r.stdout, (r.returncode, r.stdout, r.stderr[-3000:])
