@@ -119,7 +119,7 @@ int HSOpticalFlowOpenCL::run()
     }
     if (src == "-hd") {
         pnm::Image c1, c2, g1, g2;
-        if (!pnm::load(input1, c1) || !pnm::load(input2, c2)) {
+        if (!pnm::load_image(input1, c1) || !pnm::load_image(input2, c2)) {
             std::cout << "Input image error.\n";
             return -1; // HSOpticalFlowOpenCL.cpp:724,735
         }
@@ -136,12 +136,12 @@ int HSOpticalFlowOpenCL::run()
     }
     // "-cam": previous frame stays on the device, only the new frame is uploaded (:810-834)
     pnm::Image prev, cur, gprev, gcur;
-    if (!pnm::load(camera_frame(0), prev)) { std::cerr << "ERROR: capture is NULL \n"; return -1; }
+    if (!pnm::load_image(camera_frame(0), prev)) { std::cerr << "ERROR: capture is NULL \n"; return -1; }
     pnm::to_gray(prev, gprev);
     if (ensureContext(gprev.width, gprev.height) != SDK_SUCCESS) return SDK_FAILURE;
     double total = 0.0;
     int count = 0;
-    for (int i = 1; pnm::load(camera_frame(i), cur); i++) {
+    for (int i = 1; pnm::load_image(camera_frame(i), cur); i++) {
         pnm::to_gray(cur, gcur);
         if (gcur.width != gprev.width || gcur.height != gprev.height) break;
         if (solvePair(gprev, gcur, count > 0) != SDK_SUCCESS) return SDK_FAILURE;
@@ -165,7 +165,7 @@ int HSOpticalFlowOpenCL::run()
 int OpticalFlowOpenCV::runFromImg(char *input1, char *input2, char *output, float lambda, int it)
 {
     pnm::Image c1, c2;
-    if (!pnm::load(input1, c1) || !pnm::load(input2, c2) || c1.width != c2.width || c1.height != c2.height) {
+    if (!pnm::load_image(input1, c1) || !pnm::load_image(input2, c2) || c1.width != c2.width || c1.height != c2.height) {
         std::cout << "Input image error.\n";
         return -1;
     }

@@ -17,7 +17,7 @@
 #include <vector>
 
 #include "../../../include/hsflow.h"
-#include "pnm.hpp"
+#include "jpeg_baseline.hpp"
 
 #define SDK_SUCCESS 0 /* SDKUtil/include/SDKCommon.hpp:23 */
 #define SDK_FAILURE 1 /* SDKUtil/include/SDKCommon.hpp:24 */

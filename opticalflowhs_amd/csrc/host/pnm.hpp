@@ -1,6 +1,7 @@
 // pnm.hpp -- minimal binary PGM (P5) / PPM (P6) reader-writer and the drawing primitives the
 // reference used from OpenCV highgui / cxcore (cvLoadImage, cvSaveImage, cvCircle, cvLine),
-// which do not exist on this platform.  Host-side plumbing only; nothing here is on the hot path.
+// which do not exist on this platform (baseline JPEG input: jpeg_baseline.hpp).  Host-side plumbing
+// only; nothing here is on the hot path.
 #pragma once
 #include <cstdint>
 #include <cstdio>

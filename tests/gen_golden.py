@@ -101,6 +101,9 @@ def main():
         np.savez_compressed(os.path.join(OUT, "bunny_flow_l1_i50.npz"), u=u, v=v, iters=np.int32(n))
         # the second pair the reference ships, and what its CPU route drew for both pairs
         grids = {}
+        # the reference's input pictures as they are (data files, 87-146 KB each): what its command line is run on
+        for name in ("city_1.jpg", "city_2.jpg", "bunny_1.jpg", "bunny_2.jpg"):
+            shutil.copyfile(os.path.join(REF, name), os.path.join(OUT, "ref_" + name))
         for name in ("city_1.jpg", "city_2.jpg"):
             rgb = np.asarray(Image.open(os.path.join(REF, name)).convert("RGB"))
             write_pgm(os.path.join(OUT, name.replace(".jpg", "_gray.pgm")), hs_oracle.bgr2gray(rgb[:, :, ::-1]))

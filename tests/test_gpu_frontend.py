@@ -264,3 +264,18 @@ def test_classic_fused_kernel_equals_single_sweep_kernel(hs, oracle, gpu_ok):
             u, v = ctx.flow(pair=i)
             uo, vo = oracle.classic_flow(A, B, 4.0, 11)
             assert np.array_equal(u, uo) and np.array_equal(v, vo), i
+
+
+@pytest.mark.parametrize("name", ["city", "bunny"])
+def test_cli_on_the_reference_jpegs_reproduces_its_pictures(hs, gpu_ok, tmp_path, name):
+    """The reference's command lines on the reference's own JPEG files (main.cpp:16,20 defaults with the
+    10 iterations its pictures were made with): what the drop-in writes, saved as JPEG, IS the reference's
+    picture -- for the CPU route, and for the OpenCL route with Kernels.cl as shipped."""
+    pytest.importorskip("PIL")
+    import refpics
+    a, b = os.path.join(GOLDEN, "ref_%s_1.jpg" % name), os.path.join(GOLDEN, "ref_%s_2.jpg" % name)
+    out = str(tmp_path / "out.ppm")
+    _cli(["-cv", "-hd", a, b, out, ".1", "10"], tmp_path)
+    assert refpics.picture_difference(read_ppm(out), name, "cv")[0] == 0
+    _cli(["-cl", "-hd", a, b, out, "15", "10", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
+    assert refpics.picture_difference(read_ppm(out), name, "cl")[0] == 0
