@@ -131,7 +131,7 @@ int HSOpticalFlowOpenCL::run()
         std::cout << "Avg time: " << lastMs << " [ms]" << std::endl; // :755
         pnm::Image imgFlow;
         drawFlow(imgFlow);
-        if (!output.empty() && !pnm::save(output, imgFlow)) return SDK_FAILURE;
+        if (!output.empty() && !pnm::save_image(output, imgFlow)) return SDK_FAILURE;
         return 0;
     }
     // "-cam": previous frame stays on the device, only the new frame is uploaded (:810-834)
@@ -152,7 +152,7 @@ int HSOpticalFlowOpenCL::run()
             drawFlow(imgFlow);
             char name[64];
             snprintf(name, sizeof(name), "/flow_%04d.ppm", i);
-            pnm::save(std::string(getenv("HSFLOW_CAMERA_OUT")) + name, imgFlow);
+            pnm::save_image(std::string(getenv("HSFLOW_CAMERA_OUT")) + name, imgFlow);
         }
         gprev = gcur;
     }
@@ -203,7 +203,7 @@ int OpticalFlowOpenCV::runFromImg(char *input1, char *input2, char *output, floa
                 pnm::line(imgFlow, x, y, (int)(x + px / 2), (int)(y + py / 2), 255, 0, 0);
             }
         }
-    pnm::save(output, imgFlow);
+    pnm::save_image(output, imgFlow);
     std::cout << "Avg time: " << ms << " [ms]" << std::endl;
     return 0;
 }

@@ -18,6 +18,7 @@
 
 #include "../../../include/hsflow.h"
 #include "jpeg_baseline.hpp"
+#include "jpeg_encode.hpp"
 
 #define SDK_SUCCESS 0 /* SDKUtil/include/SDKCommon.hpp:23 */
 #define SDK_FAILURE 1 /* SDKUtil/include/SDKCommon.hpp:24 */

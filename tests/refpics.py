@@ -15,7 +15,8 @@ scan with the oracle has ONE sharp optimum per route, the same for both image pa
 lambda = 0.1 (main.cpp:8's LAMBDA) / alpha = 15 (main.cpp:5's ALPHA), and 10 iterations.  There,
 re-drawing the oracle's flow by the rule above (circle and line rasterised as OpenCV's cvCircle /
 cvLine do) and saving it as JPEG (quality 95, 4:2:0 -- cvSaveImage's defaults) decodes to the
-reference's picture EXACTLY: no pixel differs, in any of the four.  One sweep more or less, or
+reference's picture EXACTLY: no pixel differs, in any of the four -- in fact the encoded FILES are the
+same bytes (tests/test_jpeg.py, tests/test_gpu_frontend.py).  One sweep more or less, or
 another lambda / alpha, changes dozens of dots and lines (PSNR drops from identical to < 37 dB).
 
 What that pins: 24 360 (CPU route) + 24 360 (OpenCL route) drawn / not-drawn decisions and the

@@ -270,7 +270,8 @@ def test_classic_fused_kernel_equals_single_sweep_kernel(hs, oracle, gpu_ok):
 def test_cli_on_the_reference_jpegs_reproduces_its_pictures(hs, gpu_ok, tmp_path, name):
     """The reference's command lines on the reference's own JPEG files (main.cpp:16,20 defaults with the
     10 iterations its pictures were made with): what the drop-in writes, saved as JPEG, IS the reference's
-    picture -- for the CPU route, and for the OpenCL route with Kernels.cl as shipped."""
+    picture -- for the CPU route, and for the OpenCL route with Kernels.cl as shipped -- and, written as
+    .jpg, the reference's output file itself."""
     pytest.importorskip("PIL")
     import refpics
     a, b = os.path.join(GOLDEN, "ref_%s_1.jpg" % name), os.path.join(GOLDEN, "ref_%s_2.jpg" % name)
@@ -279,3 +280,9 @@ def test_cli_on_the_reference_jpegs_reproduces_its_pictures(hs, gpu_ok, tmp_path
     assert refpics.picture_difference(read_ppm(out), name, "cv")[0] == 0
     _cli(["-cl", "-hd", a, b, out, "15", "10", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
     assert refpics.picture_difference(read_ppm(out), name, "cl")[0] == 0
+    # ... and with a .jpg output name, like the reference's own runs: the very same FILE, byte for byte
+    out = str(tmp_path / "out.jpg")
+    _cli(["-cv", "-hd", a, b, out, ".1", "10"], tmp_path)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cv_out.jpg" % name), "rb").read()
+    _cli(["-cl", "-hd", a, b, out, "15", "10", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cl_out.jpg" % name), "rb").read()

@@ -119,3 +119,51 @@ def test_reference_inputs_give_the_committed_gray_planes(jpeg2ppm, oracle, tmp_p
             assert rgb is not None, err
             gray = oracle.bgr2gray(np.ascontiguousarray(rgb[:, :, ::-1]))
             assert np.array_equal(gray, refpics.read_pgm(os.path.join(GOLDEN, "%s_%d_gray.pgm" % (name, k)))), (name, k)
+
+
+@pytest.fixture(scope="module")
+def ppm2jpeg(tmp_path_factory):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path_factory.mktemp("jpegw") / "ppm2jpeg")
+    src = os.path.join(ROOT, "opticalflowhs_amd", "csrc", "host", "ppm2jpeg.cpp")
+    r = subprocess.run([gxx, "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", exe, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def encode_ours(exe, arr, tmp, quality=95):
+    src, dst = os.path.join(tmp, "e.ppm"), os.path.join(tmp, "e.jpg")
+    with open(src, "wb") as f:
+        f.write(b"P%d\n%d %d\n255\n" % (6 if arr.ndim == 3 else 5, arr.shape[1], arr.shape[0]))
+        f.write(np.ascontiguousarray(arr).tobytes())
+    subprocess.check_call([exe, src, dst, str(quality)])
+    return open(dst, "rb").read()
+
+
+def test_writer_is_byte_identical_to_libjpeg(ppm2jpeg, tmp_path):
+    """The CLI's JPEG writer (host/jpeg_encode.hpp: what cvSaveImage does) against PIL's encoder with the
+    same settings (quality, 4:2:0, standard tables): the same bytes, for ragged sizes, gray and colour."""
+    rng = np.random.default_rng(9)
+    for case in range(80):
+        W, H = int(rng.integers(1, 80)), int(rng.integers(1, 60))
+        gray = case % 5 == 0
+        shape = (H, W) if gray else (H, W, 3)
+        arr = rng.integers(0, 256, size=shape, dtype=np.uint8) if case % 3 else np.full(shape, 17 * (case % 15), np.uint8)
+        q = int(rng.choice([95, 95, 75, 50, 30, 100, 10]))
+        buf = io.BytesIO()
+        Image.fromarray(arr).save(buf, format="JPEG", quality=q, **({} if gray else {"subsampling": 2}))
+        assert encode_ours(ppm2jpeg, arr, str(tmp_path), q) == buf.getvalue(), (case, W, H, gray, q)
+
+
+def test_writer_reproduces_the_reference_files(ppm2jpeg, oracle, tmp_path):
+    """Oracle flow -> drawing rule -> this writer = the reference's output FILES, byte for byte (all four)."""
+    import refpics
+    for name in ("city", "bunny"):
+        A0, B0 = refpics.gray_pair(name)
+        u, v = oracle.calc_optical_flow_hs(oracle.box_blur3(A0), oracle.box_blur3(B0), refpics.LAMBDA, refpics.ITERATIONS,
+                                           epsilon=refpics.EPSILON, term_type=3)
+        assert encode_ours(ppm2jpeg, refpics.render(u, v), str(tmp_path)) == open(os.path.join(GOLDEN, "ref_%s_cv_out.jpg" % name), "rb").read()
+        u, v = oracle.classic_flow(A0, B0, refpics.ALPHA, refpics.ITERATIONS, update_v=False)
+        assert encode_ours(ppm2jpeg, refpics.render(u, v, "cl"), str(tmp_path)) == open(os.path.join(GOLDEN, "ref_%s_cl_out.jpg" % name), "rb").read()
