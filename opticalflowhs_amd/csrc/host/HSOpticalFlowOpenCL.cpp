@@ -15,13 +15,18 @@ double now_ms()
 }
 
 // Frames of the "-cam" route come from numbered files instead of a capture device:
-// $HSFLOW_CAMERA_DIR/frame_0000.pgm, frame_0001.pgm, ... until one is missing.
+// $HSFLOW_CAMERA_DIR/frame_0000.pgm (or .ppm / .jpg), frame_0001.pgm, ... until one is missing.
 std::string camera_frame(int i)
 {
     const char *dir = getenv("HSFLOW_CAMERA_DIR");
+    const std::string base = std::string(dir ? dir : ".");
     char name[64];
+    for (const char *ext : {"pgm", "ppm", "jpg"}) {
+        snprintf(name, sizeof(name), "/frame_%04d.%s", i, ext);
+        if (FILE *f = fopen((base + name).c_str(), "rb")) { fclose(f); return base + name; }
+    }
     snprintf(name, sizeof(name), "/frame_%04d.pgm", i);
-    return std::string(dir ? dir : ".") + name;
+    return base + name;
 }
 
 } // namespace
