@@ -167,6 +167,21 @@ int HSOpticalFlowOpenCL::run()
 
 // ---- GPU counterpart of OpticalFlowOpenCV (OpticalFlowHS/OpticalFlowOpenCV.cpp:7-52) --------------
 
+// arrows of the CPU route: 4-pixel grid, |.| > 1, half length (OpticalFlowOpenCV.cpp:33-46, :98-111)
+static void draw_cv_flow(pnm::Image &imgFlow, const std::vector<float> &u, const std::vector<float> &v, int W, int H)
+{
+    imgFlow.width = W; imgFlow.height = H; imgFlow.channels = 3;
+    imgFlow.data.assign((size_t)W * H * 3, 0);
+    for (int y = 0; y < H; y += 4)
+        for (int x = 0; x < W; x += 4) {
+            const float px = u[(size_t)y * W + x], py = v[(size_t)y * W + x];
+            if (px > 1 || py > 1 || px < -1 || py < -1) {
+                pnm::filled_circle(imgFlow, x, y, 2, 0, 0, 255);
+                pnm::line(imgFlow, x, y, (int)(x + px / 2), (int)(y + py / 2), 255, 0, 0);
+            }
+        }
+}
+
 int OpticalFlowOpenCV::runFromImg(char *input1, char *input2, char *output, float lambda, int it)
 {
     pnm::Image c1, c2;
@@ -196,25 +211,55 @@ int OpticalFlowOpenCV::runFromImg(char *input1, char *input2, char *output, floa
     const double ms = now_ms() - t0;
     if (st != HSFLOW_OK) { std::cout << hsflow_last_error(ctx) << std::endl; hsflow_destroy(ctx); return 1; }
     hsflow_destroy(ctx);
-    // arrows: 4-pixel grid, |.| > 1, half length (OpticalFlowOpenCV.cpp:33-46)
     pnm::Image imgFlow;
-    imgFlow.width = W; imgFlow.height = H; imgFlow.channels = 3;
-    imgFlow.data.assign((size_t)W * H * 3, 0);
-    for (int y = 0; y < H; y += 4)
-        for (int x = 0; x < W; x += 4) {
-            const float px = u[(size_t)y * W + x], py = v[(size_t)y * W + x];
-            if (px > 1 || py > 1 || px < -1 || py < -1) {
-                pnm::filled_circle(imgFlow, x, y, 2, 0, 0, 255);
-                pnm::line(imgFlow, x, y, (int)(x + px / 2), (int)(y + py / 2), 255, 0, 0);
-            }
-        }
+    draw_cv_flow(imgFlow, u, v, W, H);
     pnm::save_image(output, imgFlow);
     std::cout << "Avg time: " << ms << " [ms]" << std::endl;
     return 0;
 }
 
-int OpticalFlowOpenCV::runFromCamera(float, int)
+// The camera loop of the CPU route (OpticalFlowOpenCV.cpp:56-131) on numbered frame files instead of a
+// capture device ($HSFLOW_CAMERA_DIR, see camera_frame).  Faithful to the reference's loop, including
+// its quirk: cvSmooth works in place and the blurred new frame becomes the next old frame (:93,:117),
+// so from the second pair on the old frame enters the solver blurred TWICE.  The blurred frames never
+// leave the device: the new one is read back only to be handed in again as the next old one.
+int OpticalFlowOpenCV::runFromCamera(float lambda, int it)
 {
-    std::cout << "ERROR: capture is NULL \n"; // no capture device on this platform
-    return -1;
+    pnm::Image frame, gold, gnew;
+    if (!pnm::load_image(camera_frame(0), frame)) { std::cout << "ERROR: capture is NULL \n"; return -1; }
+    pnm::to_gray(frame, gold);                                   // cvCvtColor(imgTmp, imgOld, CV_BGR2GRAY) :79
+    const int W = gold.width, H = gold.height;
+    hsflow_ctx *ctx = nullptr;
+    if (hsflow_create(&ctx, 0, W, H, 1, nullptr, 1) != HSFLOW_OK) { std::cout << hsflow_last_error(nullptr) << std::endl; return 1; }
+    hsflow_params p;
+    hsflow_default_params(&p);                                   // ITER|EPS, eps (float)1e-6 :94
+    p.lambda = lambda;
+    p.max_iter = it;
+    std::vector<float> u((size_t)W * H), v((size_t)W * H);
+    std::vector<uint8_t> scratch((size_t)W * H);
+    double total = 0.0;
+    int count = 0;
+    for (int i = 1; pnm::load_image(camera_frame(i), frame); i++) {
+        pnm::to_gray(frame, gnew);
+        if (gnew.width != W || gnew.height != H) break;
+        const double t0 = now_ms();
+        int st = hsflow_set_frames_gray8_blur(ctx, 0, gold.data.data(), (size_t)W, gnew.data.data(), (size_t)W); // :92-93
+        if (st == HSFLOW_OK) st = hsflow_solve(ctx, &p);
+        if (st == HSFLOW_OK) st = hsflow_get_flow(ctx, 0, u.data(), (size_t)W * 4, v.data(), (size_t)W * 4);
+        total += now_ms() - t0;
+        // imgOld = imgNew (:117): the blurred new frame
+        if (st == HSFLOW_OK) st = hsflow_get_frames_u8(ctx, 0, scratch.data(), (size_t)W, gold.data.data(), (size_t)W);
+        if (st != HSFLOW_OK) { std::cout << hsflow_last_error(ctx) << std::endl; hsflow_destroy(ctx); return 1; }
+        count++;
+        if (getenv("HSFLOW_CAMERA_OUT")) {
+            pnm::Image imgFlow;
+            draw_cv_flow(imgFlow, u, v, W, H);
+            char name[64];
+            snprintf(name, sizeof(name), "/flow_%04d.ppm", i);
+            pnm::save_image(std::string(getenv("HSFLOW_CAMERA_OUT")) + name, imgFlow);
+        }
+    }
+    hsflow_destroy(ctx);
+    if (count) std::cout << "Avg time: " << total / count << " [ms]" << std::endl; // :122 (per frame)
+    return 0;
 }

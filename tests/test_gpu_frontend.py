@@ -286,3 +286,29 @@ def test_cli_on_the_reference_jpegs_reproduces_its_pictures(hs, gpu_ok, tmp_path
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cv_out.jpg" % name), "rb").read()
     _cli(["-cl", "-hd", a, b, out, "15", "10", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cl_out.jpg" % name), "rb").read()
+
+
+def test_cv_camera_route_matches_the_reference_loop(hs, oracle, gpu_ok, tmp_path):
+    """`-cv -cam` on numbered frame files: the reference's loop (OpticalFlowOpenCV.cpp:56-131) blurs in place
+    and re-uses the blurred new frame as the next old one, so from the second pair on the old frame is blurred
+    twice.  The drawings must be those of the oracle run through exactly that loop."""
+    import refpics
+    W, H, n = 160, 96, 4
+    rng = np.random.default_rng(3)
+    cam, out = tmp_path / "cam", tmp_path / "out"
+    cam.mkdir()
+    out.mkdir()
+    frames = []
+    for i in range(n):
+        A, _ = synth.translating_pair(W, H, seed=77, dx=1.5 * i, dy=-0.75 * i)
+        frames.append(A)
+        write_pnm(str(cam / ("frame_%04d.pgm" % i)), A)
+    r = _cli(["-cv", "-cam", ".1", "12"], tmp_path, {"HSFLOW_CAMERA_DIR": str(cam), "HSFLOW_CAMERA_OUT": str(out)})
+    assert "Avg time" in r.stdout
+    old = frames[0]
+    for i in range(1, n):
+        old_b, new_b = oracle.box_blur3(old), oracle.box_blur3(frames[i])
+        u, v = oracle.calc_optical_flow_hs(old_b, new_b, 0.1, 12, float(np.float32(1e-6)), ITER | EPS)
+        assert np.array_equal(read_ppm(str(out / ("flow_%04d.ppm" % i))), refpics.render(u, v)), i
+        old = new_b                                   # already blurred; blurred again next time round
+    assert not (out / ("flow_%04d.ppm" % n)).exists()
