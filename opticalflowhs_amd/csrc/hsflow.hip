@@ -776,6 +776,41 @@ int settle_pending(hsflow_ctx *c)
     return st;
 }
 
+// Replays the hipGraph cached under `key`, capturing it first if needed.  `configure` sets kernel
+// attributes (not allowed inside a capture), `enqueue` issues the launch sequence on c->stream and
+// reports how many Jacobi launches it made.  On return c->cur is where the sequence leaves the flow.
+template <class Configure, class Enqueue>
+int run_captured(hsflow_ctx *c, const GraphKey &key, Configure configure, Enqueue enqueue, int *launches)
+{
+    if (!c->stream)
+        return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
+                                     "context on a non-default stream or with own_stream");
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        int st = configure();
+        if (st) return st;
+        HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int cur0 = c->cur;
+        int n = 0;
+        st = enqueue(&n);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
+        if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+        GraphEntry ge{};
+        ge.graph = graph;
+        ge.cur_after = c->cur;
+        ge.launches = n;
+        HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+        trim_graph_cache(c);
+        it = c->graphs.emplace(key, ge).first;
+    }
+    HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
+    c->cur = it->second.cur_after;
+    *launches = it->second.launches;
+    return HSFLOW_OK;
+}
+
 // What solve_impl works out once and the three termination paths share.
 struct SolveSetup {
     float coeff;        // Ilambda = fl32(1 / fl32(lambda))
@@ -804,35 +839,23 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
     const bool zero = !p.use_previous;
     const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
     if (p.use_graph && !p.profile) {
-        if (!c->stream)
-            return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
-                                         "context on a non-default stream or with own_stream");
         GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                      c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff};
-        auto it = c->graphs.find(key);
-        if (it == c->graphs.end()) {
-            if (multi) { // function attributes are set outside the capture
+        auto configure = [&]() -> int {
+            if (multi) {
                 HS_HIP(c, launch_j(c, plan, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (rem) HS_HIP(c, launch_j(c, tail, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
             }
-            HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            const int cur0 = c->cur;
-            st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamEndCapture(c->stream, &graph);
-            if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
-            if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
-            GraphEntry ge{};
-            ge.graph = graph;
-            ge.cur_after = c->cur;
-            ge.launches = c->info.jacobi_launches;
-            HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
-            trim_graph_cache(c);
-            it = c->graphs.emplace(key, ge).first;
-        }
-        HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
-        c->cur = it->second.cur_after;
-        c->info.jacobi_launches = it->second.launches;
+            return HSFLOW_OK;
+        };
+        auto enqueue = [&](int *n) -> int {
+            const int e = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
+            *n = c->info.jacobi_launches;
+            return e;
+        };
+        int n = 0;
+        if ((st = run_captured(c, key, configure, enqueue, &n))) return st;
+        c->info.jacobi_launches = n;
     } else {
         st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
         if (st) return st;
@@ -930,34 +953,21 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             return eps_collect_enqueue(c, slots);
         };
         if (p.use_graph && !p.profile) {
-            if (!c->stream)
-                return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
-                                             "context on a non-default stream or with own_stream");
             GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                          c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff, c->epsThr};
-            auto it = c->graphs.find(key);
-            if (it == c->graphs.end()) {
-                // function attributes are set outside the capture
+            auto configure = [&]() -> int {
                 HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 HS_HIP(c, launch_j(c, plan, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (has_tail) HS_HIP(c, launch_j(c, tailp, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
-                HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                st = enqueue();
-                hipGraph_t graph = nullptr;
-                hipError_t e = hipStreamEndCapture(c->stream, &graph);
-                if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
-                if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
-                GraphEntry ge{};
-                ge.graph = graph;
-                ge.cur_after = c->cur;
-                ge.launches = launches;
-                HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
-                trim_graph_cache(c);
-            it = c->graphs.emplace(key, ge).first;
-            }
-            HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
-            c->cur = it->second.cur_after;
-            launches = it->second.launches;
+                return HSFLOW_OK;
+            };
+            auto enqueue_n = [&](int *n) -> int {
+                launches = 0;
+                const int e = enqueue();
+                *n = launches;
+                return e;
+            };
+            if ((st = run_captured(c, key, configure, enqueue_n, &launches))) return st;
             c->epsPtr = c->dEps;
             c->epsStride = 1;
         } else if ((st = enqueue())) {
