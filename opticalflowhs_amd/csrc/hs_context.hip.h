@@ -1,0 +1,113 @@
+// hs_context.hip.h -- part of libhsflow.so (one translation unit, see hsflow.hip): plan / graph types, the
+// context object behind hsflow_ctx, error plumbing.
+#pragma once
+
+namespace {
+
+constexpr int kMaxFuse = 32;        // upper bound on sweeps per fused launch
+constexpr int kLdsLimit = 160 * 1024; // bytes of LDS per CU on gfx950
+constexpr int kNumCU = 256;
+
+thread_local std::string g_create_error; // last error of a call without a context, per host thread
+
+struct FusedPlan {
+    hsk::FusedGeom g;
+    int NT, K, lds_bytes, tiles;
+};
+
+struct StripPlan {
+    hsk::StripGeom g;
+    int R, lds_bytes, tiles;
+    int fold; // 0: k_jacobi_strip (256 columns, one strip per wavefront); 1: k_jacobi_fold (128 columns, two)
+};
+
+// A launch plan for T sweeps with either multi-sweep kernel.
+struct JPlan {
+    int kind = 0; // HSFLOW_KERNEL_FUSED, HSFLOW_KERNEL_STRIP or HSFLOW_KERNEL_FOLD
+    int T = 0;
+    FusedPlan f{};
+    StripPlan s{};
+};
+
+struct GraphKey {
+    int mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev; // lr: K (fused) or R (strip)
+    float coeff;
+    float eps_thr = -1.f; // >= 0: the graph of an ITER|EPS witness pass with that threshold
+    bool operator<(const GraphKey &o) const
+    {
+        return std::tie(mode, kernel, max_iter, T, tw, th, nt, lr, cur, use_prev, coeff, eps_thr) <
+               std::tie(o.mode, o.kernel, o.max_iter, o.T, o.tw, o.th, o.nt, o.lr, o.cur, o.use_prev, o.coeff, o.eps_thr);
+    }
+};
+
+struct GraphEntry {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int cur_after, launches;
+};
+
+} // namespace
+
+struct hsflow_ctx {
+    int device = 0;
+    int W = 0, H = 0, N = 0, P = 0;
+    long long plane = 0; // elements per pair plane
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *dA = nullptr, *dB = nullptr;
+    uint32_t *dCoef = nullptr;
+    float *dE[3] = {nullptr, nullptr, nullptr}; // CLASSIC mode: Ex, Ey, Et planes (allocated on first use)
+    int coef_mode = -1;          // discretisation the current derivatives belong to
+    float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
+    unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL
+    unsigned *dEps = nullptr;   // kMaxFuse words: Eps sink of launches that do not collect it
+    unsigned *epsPtr = nullptr; // where the running launch records Eps: [sweep][epsStride] words
+    float epsThr = 0.f;         // witness launches: smallest float >= epsilon
+    unsigned *hEps = nullptr;   // page-locked read-back buffer for the per-sweep Eps words
+    size_t hEpsCap = 0;
+    int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
+    unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
+    size_t epsTilesCap = 0;
+    unsigned *dEpsAll = nullptr; // one word per sweep of a whole ITER|EPS solve (speculative run)
+    int epsAllCap = 0;
+    float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
+    void *dScratch = nullptr;   // staging for colour frames / derivative read-back
+    size_t scratch_bytes = 0;
+    int cur = 0;                // which of dU/dV holds the current flow
+    bool frames_set = false;
+    bool coef_valid = false;
+    hsflow_info info;
+    std::string err;
+    // an ITER|EPS solve enqueued by hsflow_solve_async whose early-stop check is still owed
+    struct Pending {
+        bool active = false;
+        hsflow_params params;
+        int iters = 0, slots = 0, launches = 0, cur0 = 0;
+    } pend;
+    bool force_exact = false; // the exact per-sweep pass is wanted (set while a pending solve is settled)
+    std::map<GraphKey, GraphEntry> graphs;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+hsflow_ctx *g_oneshot = nullptr; // context kept by hsflow_calc_optical_flow_hs_8u32f between calls
+std::mutex g_oneshot_mutex;
+
+int fail(hsflow_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HS_HIP(c, call)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), e_ == hipErrorOutOfMemory ? HSFLOW_E_OOM : HSFLOW_E_DEVICE,          \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+} // namespace

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     // eps_out[workgroup] = +inf if any wavefront of the workgroup did, else 0.
     // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
     // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
-    // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hsflow.hip).
+    // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hs_runtime.hip.h).
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64], then 32 floats for Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
     if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }

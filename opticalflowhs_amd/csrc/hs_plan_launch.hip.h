@@ -1,0 +1,323 @@
+// hs_plan_launch.hip.h -- part of libhsflow.so: launch planners (LDS-tile, strip / fold cost model) and the
+// kernel launch wrappers.
+#pragma once
+
+namespace {
+// ------------------------------------------------------------------------------------------
+// Tile planner for the fused kernel.  Cost model: the launch takes ceil(tiles / CUs) rounds of
+// one workgroup per CU; a round costs the region area (LDS sweeps dominate) plus a fixed part.
+// ------------------------------------------------------------------------------------------
+bool make_plan(const hsflow_ctx *c, int T, int tw, int th, int nt, FusedPlan &best)
+{
+    const int W = c->W, H = c->H;
+    const int HX = round_up(T, 4);
+    double best_cost = 1e300;
+    bool found = false;
+    const int nts[3] = {1024, 512, 256};
+    for (int nti = 0; nti < 3; nti++) {
+        const int NT = nts[nti];
+        if (nt && nt != NT) continue;
+        const int Kmax = NT == 1024 ? 3 : 4;
+        const int wg_per_cu = 1; // LDS-heavy tiles: plan for one resident workgroup per CU
+        const int cw_lo = tw ? tw : 4, cw_hi = tw ? tw : std::min(round_up(W, 4), 1024);
+        for (int CW = cw_lo; CW <= cw_hi; CW += 4) {
+            const int RW4 = (CW + 2 * HX) / 4;
+            const int ch_lo = th ? th : 1, ch_hi = th ? th : std::min(H, 1024);
+            for (int CH = ch_lo; CH <= ch_hi; CH++) {
+                const int RH = CH + 2 * T;
+                const long long G = (long long)RW4 * RH;
+                if (G > (long long)NT * Kmax) break; // CH only grows
+                const int RS = 4 * RW4 + 8;
+                const long long lds = 2LL * RS * (RH + 2) * 4;
+                if (lds > kLdsLimit) break;
+                const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
+                const long long tiles = (long long)tx * ty * c->N;
+                const int K = (int)((G + NT - 1) / NT);
+                const long long rounds = (tiles + (long long)kNumCU * wg_per_cu - 1) / ((long long)kNumCU * wg_per_cu);
+                // per-round cost ~ K sweeps-worth of work per lane * T, plus load/store of the tile
+                const double per_round = (double)K * NT * 4 * (T + 3.0) + 2000.0;
+                const double cost = (double)rounds * per_round;
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    found = true;
+                    best.NT = NT;
+                    best.K = K;
+                    best.lds_bytes = (int)lds;
+                    best.tiles = (int)tiles;
+                    hsk::FusedGeom &g = best.g;
+                    g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
+                    g.CW = CW; g.CH = CH; g.T = T; g.HX = HX;
+                    g.RW4 = RW4; g.RH = RH; g.RS = RS; g.G = (int)G;
+                    g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+template <int NT, int K, bool EPS, int LR>
+hipError_t launch_fused_t(const hsflow_ctx *c, const FusedPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool configure_only)
+{
+    auto kern = hsk::k_jacobi_fused<NT, K, EPS, LR>;
+    static bool configured[64] = {}; // per instantiation and device: raise the dynamic-LDS cap once
+    if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess; // done ahead of a stream capture
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dCoef, ui, vi, uo,
+                       vo, p.g, coeff, c->epsPtr, c->epsStride);
+    return hipGetLastError();
+}
+
+template <bool EPS, int LR>
+hipError_t launch_fused_e(const hsflow_ctx *c, const FusedPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool cfg)
+{
+#define HS_CASE(NT_, K_)                                                                          \
+    if (p.NT == NT_ && p.K == K_) return launch_fused_t<NT_, K_, EPS, LR>(c, p, ui, vi, uo, vo, coeff, cfg);
+    HS_CASE(1024, 1) HS_CASE(1024, 2) HS_CASE(1024, 3)
+    HS_CASE(512, 1) HS_CASE(512, 2) HS_CASE(512, 3) HS_CASE(512, 4)
+    HS_CASE(256, 1) HS_CASE(256, 2) HS_CASE(256, 3) HS_CASE(256, 4)
+#undef HS_CASE
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int lr, const float *ui,
+                        const float *vi, float *uo, float *vo, float coeff, bool cfg = false)
+{
+    if (eps) return lr ? launch_fused_e<true, 1>(c, p, ui, vi, uo, vo, coeff, cfg)
+                       : launch_fused_e<true, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
+    return lr ? launch_fused_e<false, 1>(c, p, ui, vi, uo, vo, coeff, cfg)
+              : launch_fused_e<false, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
+}
+
+
+template <int NT, int K>
+hipError_t launch_classic_fused_t(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
+                                  float *uo, float *vo, float alpha2)
+{
+    auto kern = write_v ? hsk::k_jacobi_classic_fused<NT, K, true> : hsk::k_jacobi_classic_fused<NT, K, false>;
+    static bool configured[2][64] = {};
+    if (p.lds_bytes > 32 * 1024 && !configured[write_v][c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[write_v][c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dE[0], c->dE[1], c->dE[2], ui, vi, uo, vo, p.g, alpha2);
+    return hipGetLastError();
+}
+
+hipError_t launch_classic_fused(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
+                                float *uo, float *vo, float alpha2)
+{
+#define HS_CASE(NT_, K_)                                                                          \
+    if (p.NT == NT_ && p.K == K_) return launch_classic_fused_t<NT_, K_>(c, p, write_v, ui, vi, uo, vo, alpha2);
+    HS_CASE(1024, 1) HS_CASE(1024, 2) HS_CASE(1024, 3)
+    HS_CASE(512, 1) HS_CASE(512, 2) HS_CASE(512, 3) HS_CASE(512, 4)
+    HS_CASE(256, 1) HS_CASE(256, 2) HS_CASE(256, 3) HS_CASE(256, 4)
+#undef HS_CASE
+    return hipErrorInvalidConfiguration;
+}
+
+// ------------------------------------------------------------------------------------------
+// Planner for the strip kernel: rows per lane R and wavefronts per workgroup NW.
+// Register budget fixes the wavefronts a SIMD can hold: R <= 5 -> 4, R = 6 -> 3, R <= 8 -> 2.
+// ------------------------------------------------------------------------------------------
+
+// Cost model (shader cycles at ~2.2 GHz), fitted to in-kernel phase stamps on MI355X at 1080p
+// (tools/stamps.py; profiles/): one launch = fixed launch/drain gap + per round [tile load +
+// T sweeps], where a sweep costs ~1.5 x (VALU time of the busiest SIMD + LDS edge-row exchange).
+int strip_max_waves(int R, int fold) { const int r = fold ? R + 1 : R; return r <= 5 ? 16 : (r <= 6 ? 12 : 8); }
+
+
+double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double image_pixels, int *wg_per_cu_out = nullptr)
+{
+    // Parameters fitted (least squares on log time, rms 8 %) to profiles/r01_sweep_1080p_strip5.csv,
+    // r01_sweep_4k_b.csv and r01_sweep_batch16.csv.  The sweep is VALU-issue bound (~34 instructions
+    // per row per wavefront, ~4.2 cycles each per SIMD with 4 resident wavefronts, more with fewer);
+    // a launch boundary costs ~2.7 us plus the L2 write-back of the 8 bytes per pixel just stored.
+    const int per_simd = strip_max_waves(R, fold) / 4;
+    const int lds = NW * (fold ? 4096 : 8192);
+    const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
+    if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
+    const long long slots = (long long)kNumCU * wg_per_cu;
+    const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // WGs sharing a CU
+    const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
+    const double cpi = wps >= 3.5 ? 4.2 : (wps >= 2.5 ? 5.6 : (wps >= 1.5 ? 6.5 : 8.0));
+    const int rows_per_lane = fold ? 2 * R : R;
+    const double halo_frac = std::min(1.0, 2.0 * T / (double)(NW * rows_per_lane));
+    const double instr_per_row = fold ? 42.0 : 34.0;
+    const double valu = std::max(wps, 1.0) * R * instr_per_row * cpi * (1.0 - 0.45 * halo_frac);
+    const double exchange = 300.0 + (fold ? 12.0 : 20.0) * NW * conc;
+    const double sweep = valu + exchange;
+    double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
+    if (conc > 1) load *= 0.4; // another workgroup's sweeps hide part of it
+    const double r = (double)tiles / (double)slots;
+    const double rounds = conc == 1 ? std::ceil(r) : std::max(1.0, r + 0.7);
+    return 6000.0 + 6e-4 * 8.0 * image_pixels + rounds * (load + T * sweep);
+}
+
+bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold, StripPlan &best, double *cost_out = nullptr)
+{
+    const int W = c->W, H = c->H;
+    const int HX = round_up(T, 4);
+    const int CW = (fold ? 128 : 256) - 2 * HX;
+    if (CW < 4) return false;
+    double best_cost = 1e300;
+    bool found = false;
+    for (int R = 1; R <= 8; R++) {
+        if (rows && rows != R) continue;
+        for (int NW = 1; NW <= strip_max_waves(R, fold); NW++) {
+            if (threads && threads != NW * 64) continue;
+            const int CH = NW * R * (fold ? 2 : 1) - 2 * T;
+            if (CH < 1) continue;
+            const int lds = NW * (fold ? 4096 : 8192) + (fold ? 128 : 256); // edge-row exchange + 32 floats for Eps (+ sweep counters)
+            if (lds > kLdsLimit) continue;
+            const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
+            const long long tiles = (long long)tx * ty * c->N;
+            const double cost = strip_launch_cost(T, R, NW, tiles, fold, (double)W * H * c->N);
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                found = true;
+                best.R = R;
+                best.fold = fold;
+                best.lds_bytes = lds;
+                best.tiles = (int)tiles;
+                hsk::StripGeom &g = best.g;
+                g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
+                g.T = T; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
+                g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
+            }
+        }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return found;
+}
+
+// Sweeps per launch for a budget of `iters` sweeps: minimise the modelled time of the whole solve
+// (full launches of T plus one tail launch of iters % T).
+int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fold)
+{
+    double best = 1e300;
+    int bestT = 1;
+    for (int T = 1; T <= std::min(iters, 24); T++) {
+        StripPlan sp;
+        double cfull = 0, ctail = 0;
+        if (!make_strip_plan(c, T, p.strip_rows, p.threads, fold, sp, &cfull)) continue;
+        const int rem = iters % T;
+        if (rem && !make_strip_plan(c, rem, p.strip_rows, p.threads, fold, sp, &ctail)) continue;
+        const double total = (iters / T) * cfull + (rem ? ctail : 0.0);
+        if (total < best) { best = total; bestT = T; }
+    }
+    return bestT;
+}
+
+template <int R, int NTMAX, int EPS, bool FOLD> // EPS: 0 none, 1 every sweep, 2 witness (strip kernel only)
+hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool configure_only)
+{
+    auto kern = [] {
+        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS>;
+        else return hsk::k_jacobi_strip<R, NTMAX, EPS>;
+    }();
+    static bool configured[64] = {};
+    if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
+    return hipGetLastError();
+}
+
+template <int EPS, bool FOLD>
+hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool cfg)
+{
+    switch (p.R) {
+    case 1: return launch_strip_t<1, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 2: return launch_strip_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 3: return launch_strip_t<3, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 4: return launch_strip_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5:
+        if (!FOLD && EPS && p.g.NW <= 12) return launch_strip_t<5, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+        return launch_strip_t<5, FOLD ? 768 : 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 6: return launch_strip_t<6, FOLD ? 512 : 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 7: return launch_strip_t<7, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 8: return launch_strip_t<8, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)
+{
+    out.kind = kind;
+    out.T = T;
+    if (kind == HSFLOW_KERNEL_STRIP) return make_strip_plan(c, T, p.strip_rows, p.threads, 0, out.s);
+    if (kind == HSFLOW_KERNEL_FOLD) return make_strip_plan(c, T, p.strip_rows, p.threads, 1, out.s);
+    return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
+}
+
+// eps: 0 none, 1 Eps of every sweep, 2 witness (strip kernel only: one lower bound per launch)
+hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *ui, const float *vi,
+                    float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0)
+{
+    if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
+        StripPlan sp = pl.s;
+        sp.g.zero_in = zero_in;
+        if (sp.fold) return eps == 2 ? launch_strip_e<2, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                            : eps  ? launch_strip_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                   : launch_strip_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        return eps == 2 ? launch_strip_e<2, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+               : eps  ? launch_strip_e<1, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                      : launch_strip_e<0, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
+    }
+    FusedPlan fp = pl.f;
+    fp.g.zero_in = zero_in;
+    return launch_fused(c, fp, eps != 0, 1, ui, vi, uo, vo, coeff, cfg);
+}
+
+void plan_to_info(hsflow_ctx *c, const JPlan &pl)
+{
+    hsflow_info &i = c->info;
+    i.fuse_steps = pl.T;
+    if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
+        i.tile_w = pl.s.g.CW; i.tile_h = pl.s.g.CH; i.threads = pl.s.g.NW * 64;
+        i.groups_per_thread = pl.s.R; i.tiles = pl.s.tiles; i.lds_bytes = pl.s.lds_bytes;
+    } else {
+        i.tile_w = pl.f.g.CW; i.tile_h = pl.f.g.CH; i.threads = pl.f.NT;
+        i.groups_per_thread = pl.f.K; i.tiles = pl.f.tiles; i.lds_bytes = pl.f.lds_bytes;
+    }
+}
+
+hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const float *vi, float *uo,
+                         float *vo, float coeff, int zero_in = 0)
+{
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+#define HS_SIMPLE(E, Z)                                                                            \
+    hipLaunchKernelGGL((hsk::k_jacobi_simple<E, Z>), grid, block, 0, c->stream, c->dCoef, ui, vi, uo, vo, \
+                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr)
+    if (eps) { if (zero_in) HS_SIMPLE(true, true); else HS_SIMPLE(true, false); }
+    else { if (zero_in) HS_SIMPLE(false, true); else HS_SIMPLE(false, false); }
+#undef HS_SIMPLE
+    return hipGetLastError();
+}
+
+hipError_t launch_deriv(const hsflow_ctx *c)
+{
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    hipLaunchKernelGGL(hsk::k_deriv_cv, grid, block, 0, c->stream, c->dA, c->dB, c->dCoef, c->W, c->H,
+                       c->P, c->plane);
+    return hipGetLastError();
+}
+
+} // namespace

@@ -1,0 +1,217 @@
+// hs_runtime.hip.h -- part of libhsflow.so: graph cache, HIP-event profiler, Eps buffers and read-back,
+// diagnostic stamps.
+#pragma once
+
+namespace {
+// The graph cache is keyed by everything a captured launch sequence depends on (sizes, kernel shape,
+// lambda, epsilon ...); a caller that varies those from call to call must not grow it without bound.
+constexpr size_t kMaxGraphs = 32;
+void trim_graph_cache(hsflow_ctx *c)
+{
+    if (c->graphs.size() < kMaxGraphs) return;
+    hipStreamSynchronize(c->stream); // no replay of an old graph may still be running
+    for (auto &kv : c->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    c->graphs.clear();
+}
+
+int check_ctx(hsflow_ctx *c, int pair)
+{
+    if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
+    if (pair < 0 || pair >= c->N) return fail(c, HSFLOW_E_ARG, "pair index out of range");
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HSFLOW_E_DEVICE, "hipSetDevice failed");
+    return HSFLOW_OK;
+}
+
+struct Profiler { // brackets kernels with events when params.profile is set
+    hsflow_ctx *c;
+    bool on;
+    std::vector<std::pair<int, size_t>> marks; // (kind, index of start event); kind 0 deriv, 1 jacobi
+    size_t used = 0;
+    hipEvent_t ev(size_t i)
+    {
+        while (c->events.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            c->events.push_back(e);
+        }
+        return c->events[i];
+    }
+    void begin(int kind)
+    {
+        if (!on) return;
+        marks.push_back({kind, used});
+        hipEventRecord(ev(used), c->stream);
+        used++;
+    }
+    void end()
+    {
+        if (!on) return;
+        hipEventRecord(ev(used), c->stream);
+        used++;
+    }
+    void collect()
+    {
+        if (!on || marks.empty()) return;
+        hipStreamSynchronize(c->stream);
+        float d = 0, j = 0, t = 0;
+        for (auto &m : marks) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, c->events[m.second], c->events[m.second + 1]);
+            (m.first == 0 ? d : j) += ms;
+        }
+        hipEventElapsedTime(&t, c->events[marks.front().second], c->events[used - 1]);
+        c->info.deriv_ms = d;
+        c->info.jacobi_ms = j;
+        c->info.solve_ms = t;
+    }
+};
+
+// Enqueue derivative pass + `iters` Jacobi sweeps (no host synchronisation inside).
+int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters, int kernel, int T,
+                  const JPlan *plan, const JPlan *tail_plan, Profiler &prof, bool do_deriv, bool zero_flow)
+{
+    // u = v = 0 at the start (reference behaviour, use_previous = 0): instead of clearing two
+    // planes and reading them back, the first launch is told that its input is zero.
+    int zero_in = zero_flow ? 1 : 0;
+    if (zero_flow) c->cur = 0;
+    if (do_deriv) {
+        prof.begin(0);
+        HS_HIP(c, launch_deriv(c));
+        prof.end();
+    }
+    int left = iters, launches = 0;
+    while (left > 0) {
+        const int a = c->cur, b = a ^ 1;
+        if (kernel == HSFLOW_KERNEL_SIMPLE) {
+            prof.begin(1);
+            HS_HIP(c, launch_simple(c, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, zero_in));
+            prof.end();
+            left -= 1;
+        } else {
+            const JPlan *pl = (left >= T) ? plan : tail_plan;
+            prof.begin(1);
+            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in));
+            prof.end();
+            left -= pl->T;
+        }
+        c->cur = b;
+        zero_in = 0;
+        launches++;
+    }
+    c->info.jacobi_launches = launches;
+    (void)p;
+    return HSFLOW_OK;
+}
+
+// Eps bookkeeping of an EPS-terminated solve: `sweeps` rows of `stride` words, cleared, plus the
+// reduction of the rows into dEpsAll[0..sweeps).
+// Buffers for `sweeps` Eps words of `stride` workgroups each (device) and their host copy; allocation
+// only, so that what follows can be captured in a graph.
+int eps_reserve(hsflow_ctx *c, int sweeps, int stride)
+{
+    const size_t need = (size_t)sweeps * stride;
+    if (c->epsTilesCap < need) {
+        hipFree(c->dEpsTiles);
+        c->dEpsTiles = nullptr; c->epsTilesCap = 0;
+        HS_HIP(c, hipMalloc((void **)&c->dEpsTiles, need * sizeof(unsigned)));
+        c->epsTilesCap = need;
+    }
+    if (c->epsAllCap < sweeps) {
+        hipFree(c->dEpsAll);
+        c->dEpsAll = nullptr; c->epsAllCap = 0;
+        HS_HIP(c, hipMalloc((void **)&c->dEpsAll, (size_t)sweeps * sizeof(unsigned)));
+        c->epsAllCap = sweeps;
+    }
+    if (c->hEpsCap < (size_t)sweeps) {
+        HS_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still write the old buffer
+        if (c->hEps) hipHostFree(c->hEps);
+        c->hEps = nullptr; c->hEpsCap = 0;
+        const size_t cap = std::max<size_t>(256, (size_t)sweeps * 2);
+        HS_HIP(c, hipHostMalloc((void **)&c->hEps, cap * sizeof(unsigned), hipHostMallocDefault));
+        c->hEpsCap = cap;
+    }
+    c->epsStride = stride;
+    return HSFLOW_OK;
+}
+
+int eps_clear(hsflow_ctx *c, int sweeps, int stride)
+{
+    HS_HIP(c, hipMemsetAsync(c->dEpsTiles, 0, (size_t)sweeps * stride * sizeof(unsigned), c->stream));
+    return HSFLOW_OK;
+}
+
+int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
+{
+    const int st = eps_reserve(c, sweeps, stride);
+    return st ? st : eps_clear(c, sweeps, stride);
+}
+
+int eps_collect_enqueue(hsflow_ctx *c, int sweeps) // buffers from eps_reserve; nothing allocated here
+{
+    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
+    HS_HIP(c, hipGetLastError());
+    HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    c->epsPtr = c->dEps;
+    c->epsStride = 1;
+    return HSFLOW_OK;
+}
+
+int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
+{
+    int st = eps_collect_enqueue(c, sweeps);
+    if (st) return st;
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    host.assign(c->hEps, c->hEps + sweeps);
+    return HSFLOW_OK;
+}
+
+// Witness slots of a speculative ITER|EPS pass (host copy): true if they prove that the early stop
+// cannot have fired before the budget ran out; *last = Eps of the final sweep.
+bool witness_proven(const unsigned *w, int slots, double epsilon, float *last)
+{
+    float e = 0.f;
+    for (int i = 0; i < slots; i++) {
+        std::memcpy(&e, &w[i], sizeof(float));
+        if (!((double)e >= epsilon) && i != slots - 1) return false; // a stop at the very last sweep = the budget
+    }
+    *last = e;
+    return true;
+}
+
+int plan_eps_stride(int kernel, const JPlan &pl) { return (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) ? pl.s.tiles : 1; }
+
+// Diagnostic only: with HSFLOW_DEBUG_STAMPS=<file> every strip launch records per-workgroup phase
+// stamps (8 x u64) and hsflow_solve appends those of the LAST launch to <file> as text.
+constexpr int kStampTiles = 65536;
+void dump_stamps(hsflow_ctx *c, int tiles)
+{
+    const char *path = getenv("HSFLOW_DEBUG_STAMPS");
+    if (!path || !c->dStamps) return;
+    tiles = std::min(tiles, kStampTiles);
+    std::vector<unsigned long long> h((size_t)tiles * 8);
+    if (hipMemcpy(h.data(), c->dStamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "# solve tiles=%d T=%d R=%d threads=%d\n", tiles, c->info.fuse_steps, c->info.groups_per_thread, c->info.threads);
+    for (int i = 0; i < tiles; i++) {
+        const unsigned long long *o = &h[(size_t)i * 8];
+        fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0],
+                o[5] - o[4], o[6], o[7]);
+    }
+    fclose(f);
+}
+
+int pick_T(int max_iter, int requested)
+{
+    if (requested > 0) return std::min(requested, kMaxFuse);
+    // default sweeps per launch; prefer a divisor of max_iter near 8 so that launches are uniform
+    const int pref[] = {8, 10, 7, 9, 6, 12, 5, 4};
+    for (int t : pref)
+        if (max_iter % t == 0) return t;
+    return std::min(8, std::max(1, max_iter));
+}
+
+} // namespace

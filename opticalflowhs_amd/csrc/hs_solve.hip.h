@@ -1,0 +1,568 @@
+// hs_solve.hip.h -- part of libhsflow.so: the solve paths (classic mode; CV mode with a fixed sweep count,
+// speculative ITER|EPS with witness launches, EPS-only chunks) and the deferred check of asynchronous solves.
+#pragma once
+
+namespace {
+// CLASSIC mode (Kernels.cl semantics, v restored): derivatives once, then max_iter fused
+// average+update sweeps, one launch each.  The reference loop has no other stop rule
+// (HSOpticalFlowOpenCL.cpp:750-751), so only ITER termination is accepted.
+int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
+{
+    if (p.term_type != HSFLOW_TERM_ITER) return fail(c, HSFLOW_E_ARG, "CLASSIC mode supports ITER termination only");
+    if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+    if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
+    if (p.use_graph || (async && p.profile)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: use_graph / async profiling not supported");
+    const size_t px = (size_t)c->plane * c->N;
+    for (int i = 0; i < 3; i++)
+        if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
+    Profiler prof{c, p.profile != 0};
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC)) {
+        prof.begin(0);
+        hipLaunchKernelGGL(hsk::k_deriv_classic, grid, block, 0, c->stream, c->dA, c->dB, c->dE[0], c->dE[1], c->dE[2],
+                           c->W, c->H, c->P, c->plane);
+        HS_HIP(c, hipGetLastError());
+        prof.end();
+    }
+    c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CLASSIC;
+    const float a2 = p.alpha * p.alpha; // Kernels.cl:85
+    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
+    int zero = p.use_previous ? 0 : 1;
+    if (zero) c->cur = 0;
+    if (p.kernel != HSFLOW_KERNEL_SIMPLE) {
+        // several sweeps per launch on an LDS tile (k_jacobi_classic_fused)
+        if (p.kernel != HSFLOW_KERNEL_AUTO && p.kernel != HSFLOW_KERNEL_FUSED)
+            return fail(c, HSFLOW_E_ARG, "CLASSIC mode has the simple and the fused (LDS tile) kernels only");
+        // 18 LDS values per plane and group and an IEEE division make a sweep dearer than in CV mode:
+        // the halo pays off up to about 6 sweeps per launch (tools/sweep_classic.py on MI355X)
+        const int T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
+        FusedPlan plan;
+        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, plan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
+        int done = 0, launches = 0;
+        while (done < p.max_iter) {
+            const int chunk = std::min(T, p.max_iter - done);
+            FusedPlan cp = plan;
+            if (chunk != T && !make_plan(c, chunk, p.tile_w, p.tile_h, p.threads, cp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible tile for the tail launch");
+            cp.g.zero_in = zero;
+            const int a = c->cur, b = a ^ 1;
+            prof.begin(1);
+            hipError_t e = launch_classic_fused(c, cp, write_v, c->dU[a], c->dV[a], c->dU[b], c->dV[b], a2);
+            prof.end();
+            HS_HIP(c, e);
+            c->cur = b;
+            zero = 0;
+            done += chunk;
+            launches++;
+        }
+        hsflow_info &i = c->info;
+        i.kernel = HSFLOW_KERNEL_FUSED; i.fuse_steps = T; i.tile_w = plan.g.CW; i.tile_h = plan.g.CH; i.threads = plan.NT;
+        i.groups_per_thread = plan.K; i.tiles = plan.tiles; i.lds_bytes = plan.lds_bytes; i.jacobi_launches = launches;
+        i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
+        if (!async) {
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            prof.collect();
+        }
+        return HSFLOW_OK;
+    }
+    for (int it = 0; it < p.max_iter; it++) {
+        const int a = c->cur, b = a ^ 1;
+        prof.begin(1);
+        auto kern = zero ? (write_v ? hsk::k_jacobi_classic<true, true> : hsk::k_jacobi_classic<true, false>)
+                         : (write_v ? hsk::k_jacobi_classic<false, true> : hsk::k_jacobi_classic<false, false>);
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2], c->dU[a], c->dV[a], c->dU[b], c->dV[b],
+                           c->W, c->H, c->P, c->plane, a2);
+        HS_HIP(c, hipGetLastError());
+        prof.end();
+        c->cur = b;
+        zero = 0;
+    }
+    hsflow_info &i = c->info;
+    i.kernel = HSFLOW_KERNEL_SIMPLE; i.fuse_steps = 1; i.tile_w = i.tile_h = 0; i.threads = 256;
+    i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0; i.jacobi_launches = p.max_iter;
+    i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
+    if (!async) {
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        prof.collect();
+    }
+    return HSFLOW_OK;
+}
+
+int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async);
+
+// Settles an ITER|EPS solve that hsflow_solve_async left unverified: waits for the stream, looks at the
+// witness words and, if they do not prove "no early stop", runs the exact pass from the saved start.
+int settle_pending(hsflow_ctx *c)
+{
+    if (!c->pend.active) return HSFLOW_OK;
+    c->pend.active = false;
+    HS_HIP(c, hipSetDevice(c->device));
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    float last = 0.f;
+    if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last)) {
+        c->info.iterations_done = c->pend.iters;
+        c->info.last_eps = last;
+        return HSFLOW_OK;
+    }
+    hsflow_params q = c->pend.params;
+    q.reuse_derivatives = 1; // the coefficient plane of that solve is still in place
+    if (q.use_previous) {
+        const size_t px = (size_t)c->plane * c->N;
+        c->cur = c->pend.cur0;
+        HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->force_exact = true;
+    const int st = solve_impl(c, &q, false);
+    c->force_exact = false;
+    c->info.eps_rerun = 1;
+    c->info.jacobi_launches += c->pend.launches;
+    return st;
+}
+
+// Replays the hipGraph cached under `key`, capturing it first if needed.  `configure` sets kernel
+// attributes (not allowed inside a capture), `enqueue` issues the launch sequence on c->stream and
+// reports how many Jacobi launches it made.  On return c->cur is where the sequence leaves the flow.
+template <class Configure, class Enqueue>
+int run_captured(hsflow_ctx *c, const GraphKey &key, Configure configure, Enqueue enqueue, int *launches)
+{
+    if (!c->stream)
+        return fail(c, HSFLOW_E_ARG, "use_graph: the default (NULL) stream cannot be captured; create the "
+                                     "context on a non-default stream or with own_stream");
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        int st = configure();
+        if (st) return st;
+        HS_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int cur0 = c->cur;
+        int n = 0;
+        st = enqueue(&n);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (st) { if (graph) hipGraphDestroy(graph); c->cur = cur0; return st; }
+        if (e != hipSuccess) { c->cur = cur0; return fail(c, HSFLOW_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+        GraphEntry ge{};
+        ge.graph = graph;
+        ge.cur_after = c->cur;
+        ge.launches = n;
+        HS_HIP(c, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+        trim_graph_cache(c);
+        it = c->graphs.emplace(key, ge).first;
+    }
+    HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
+    c->cur = it->second.cur_after;
+    *launches = it->second.launches;
+    return HSFLOW_OK;
+}
+
+// What solve_impl works out once and the three termination paths share.
+struct SolveSetup {
+    float coeff;        // Ilambda = fl32(1 / fl32(lambda))
+    int kernel;         // kernel actually used (AUTO resolved)
+    bool multi;         // several sweeps per launch (every kernel but the simple one)
+    bool use_iter, use_eps;
+    long long budget;   // sweep budget (huge when ITER does not apply)
+    int T;              // sweeps per full launch
+    JPlan plan;         // launch plan for T sweeps
+};
+
+// ITER termination: a fixed sweep count, nothing on the host between launches (optionally one hipGraph).
+int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Profiler &prof, bool async)
+{
+    const float coeff = S.coeff;
+    const int kernel = S.kernel, T = S.T;
+    const bool multi = S.multi;
+    const JPlan &plan = S.plan;
+    int st = HSFLOW_OK;
+    const long long budget = S.budget;
+    JPlan tail;
+    const int iters = (int)budget;
+    const int rem = multi ? iters % T : 0;
+    if (rem && !make_jplan(c, kernel, rem, p, tail))
+        return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
+    const bool zero = !p.use_previous;
+    const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
+    if (p.use_graph && !p.profile) {
+        GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+                     c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff};
+        auto configure = [&]() -> int {
+            if (multi) {
+                HS_HIP(c, launch_j(c, plan, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (rem) HS_HIP(c, launch_j(c, tail, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
+            }
+            return HSFLOW_OK;
+        };
+        auto enqueue = [&](int *n) -> int {
+            const int e = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
+            *n = c->info.jacobi_launches;
+            return e;
+        };
+        int n = 0;
+        if ((st = run_captured(c, key, configure, enqueue, &n))) return st;
+        c->info.jacobi_launches = n;
+    } else {
+        st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
+        if (st) return st;
+    }
+    c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CV;
+    c->info.iterations_done = iters;
+    if (!async) {
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        prof.collect();
+        if (c->dStamps && (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)) dump_stamps(c, plan.s.tiles);
+    }
+    return HSFLOW_OK;
+}
+
+// ITER|EPS -- the way the reference calls the solver (OpticalFlowOpenCV.cpp:29).  On real image
+// pairs Eps never drops below 1e-6 within the sweep budget, so the budget is run SPECULATIVELY at
+// full speed (no host round trip between launches) while every sweep records its Eps on the device;
+// one read-back at the end finds the first sweep k with Eps_k < epsilon.  If there is none the
+// result stands; otherwise exactly k sweeps are re-run from the saved starting flow, which
+// reproduces the oracle's stopping sweep.
+int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Profiler &prof, bool async)
+{
+    const float coeff = S.coeff;
+    const int kernel = S.kernel, T = S.T;
+    const bool multi = S.multi;
+    const JPlan &plan = S.plan;
+    int st = HSFLOW_OK;
+    const long long budget = S.budget;
+    const int iters = (int)budget;
+    const size_t px = (size_t)c->plane * c->N;
+    const bool witness = (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact;
+    const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
+    if (p.use_previous) { // the starting flow is kept: the ping-pong buffers get overwritten
+        if (!c->dUb) HS_HIP(c, hipMalloc((void **)&c->dUb, px * sizeof(float)));
+        if (!c->dVb) HS_HIP(c, hipMalloc((void **)&c->dVb, px * sizeof(float)));
+    }
+    auto save_start = [&]() -> int {
+        if (!p.use_previous) return HSFLOW_OK;
+        HS_HIP(c, hipMemcpyAsync(c->dUb, c->dU[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HS_HIP(c, hipMemcpyAsync(c->dVb, c->dV[c->cur], px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        return HSFLOW_OK;
+    };
+    // every launch of this solve uses the same number of workgroups or fewer (tail): stride = max
+    int stride = multi ? plan_eps_stride(kernel, plan) : 1;
+    JPlan tailp;
+    const bool has_tail = multi && iters % T;
+    if (has_tail) {
+        if (!make_jplan(c, kernel, iters % T, p, tailp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+        stride = std::max(stride, plan_eps_stride(kernel, tailp));
+    }
+    int launches = 0;
+    if (witness) {
+        // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
+        // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
+        // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch measures every
+        // sweep (it also provides last_eps).  If every bound holds and no sweep of the last launch
+        // but possibly its final one fell below epsilon, the early stop cannot have fired before the
+        // budget ran out and the result stands.  Otherwise (a flat or converged input) the exact
+        // per-sweep path below starts over from the saved flow.
+        // threshold as the smallest float >= epsilon: "change >= epsThr" then implies "Eps >= epsilon"
+        c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
+        if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
+        const int n_launch = (iters + T - 1) / T;
+        const int last_chunk = iters - (n_launch - 1) * T;
+        const int slots = (n_launch - 1) + last_chunk;
+        if ((st = eps_reserve(c, slots, stride))) return st;
+        const int cur0 = c->cur;
+        // the whole pass as one enqueue sequence (nothing allocated, nothing synchronised: capturable)
+        auto enqueue = [&]() -> int {
+            int e0 = save_start();
+            if (e0) return e0;
+            c->epsStride = stride;
+            if ((e0 = eps_clear(c, slots, stride))) return e0;
+            if (do_deriv) {
+                prof.begin(0);
+                HS_HIP(c, launch_deriv(c));
+                prof.end();
+            }
+            int zero_w = p.use_previous ? 0 : 1;
+            if (zero_w) c->cur = 0;
+            for (int L = 0; L < n_launch; L++) {
+                const bool is_last = L == n_launch - 1;
+                const JPlan &cp = (is_last && last_chunk != T) ? tailp : plan;
+                const int a = c->cur, b = a ^ 1;
+                c->epsPtr = c->dEpsTiles + (size_t)L * stride;
+                prof.begin(1);
+                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w);
+                prof.end();
+                HS_HIP(c, e);
+                c->cur = b;
+                zero_w = 0;
+                launches++;
+            }
+            return eps_collect_enqueue(c, slots);
+        };
+        if (p.use_graph && !p.profile) {
+            GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+                         c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff, c->epsThr};
+            auto configure = [&]() -> int {
+                HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                HS_HIP(c, launch_j(c, plan, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (has_tail) HS_HIP(c, launch_j(c, tailp, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                return HSFLOW_OK;
+            };
+            auto enqueue_n = [&](int *n) -> int {
+                launches = 0;
+                const int e = enqueue();
+                *n = launches;
+                return e;
+            };
+            if ((st = run_captured(c, key, configure, enqueue_n, &launches))) return st;
+            c->epsPtr = c->dEps;
+            c->epsStride = 1;
+        } else if ((st = enqueue())) {
+            return st;
+        }
+        c->coef_valid = true;
+        c->coef_mode = HSFLOW_MODE_CV;
+        if (async) { // the check is owed: hsflow_synchronize (or the next call that needs results) settles it
+            c->pend.active = true;
+            c->pend.params = p;
+            c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
+            c->info.iterations_done = iters;
+            c->info.jacobi_launches = launches;
+            return HSFLOW_OK;
+        }
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned> hw(c->hEps, c->hEps + slots);
+
+        float last = 0.f;
+        if (witness_proven(hw.data(), slots, p.epsilon, &last)) {
+            c->info.iterations_done = iters;
+            c->info.last_eps = last;
+            c->info.jacobi_launches = launches;
+            prof.collect();
+            return HSFLOW_OK;
+        }
+        c->info.eps_rerun = 1;
+        // not proven: restore the starting flow and measure every sweep
+        if (p.use_previous) {
+            c->cur = cur0;
+            HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if ((st = eps_prepare(c, iters, stride))) return st;
+    } else {
+        if ((st = save_start())) return st;
+        if ((st = eps_prepare(c, iters, stride))) return st;
+        if (do_deriv) {
+            prof.begin(0);
+            HS_HIP(c, launch_deriv(c));
+            prof.end();
+        }
+        c->coef_valid = true;
+        c->coef_mode = HSFLOW_MODE_CV;
+    }
+    int zero_in = p.use_previous ? 0 : 1, done = 0;
+    if (zero_in) c->cur = 0;
+    while (done < iters) {
+        const int chunk = multi ? std::min(T, iters - done) : 1;
+        JPlan cp = plan;
+        if (multi && chunk != T && !make_jplan(c, kernel, chunk, p, cp))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+        const int a = c->cur, b = a ^ 1;
+        c->epsPtr = c->dEpsTiles + (size_t)done * stride;
+        prof.begin(1);
+        hipError_t e = multi ? launch_j(c, cp, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in)
+                             : launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, zero_in);
+        prof.end();
+        HS_HIP(c, e);
+        c->cur = b;
+        zero_in = 0;
+        done += chunk;
+        launches++;
+    }
+    std::vector<unsigned> heps;
+    if ((st = eps_collect(c, iters, heps))) return st;
+    int hit = -1;
+    float last = 0.f;
+    for (int s2 = 0; s2 < iters; s2++) {
+        std::memcpy(&last, &heps[(size_t)s2], sizeof(float));
+        if ((double)last < p.epsilon) { hit = s2; break; }
+    }
+    if (hit >= 0 && hit + 1 < iters) { // converged early: redo exactly hit+1 sweeps from the start
+        const int k = hit + 1;
+        if (p.use_previous) {
+            HS_HIP(c, hipMemcpyAsync(c->dU[c->cur], c->dUb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HS_HIP(c, hipMemcpyAsync(c->dV[c->cur], c->dVb, px * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        JPlan kp, kt;
+        int Tk = 1;
+        if (multi) {
+            Tk = std::min(T, k);
+            if (!make_jplan(c, kernel, Tk, p, kp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the re-run");
+            if (k % Tk && !make_jplan(c, kernel, k % Tk, p, kt)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the re-run tail");
+        }
+        st = enqueue_fixed(c, p, coeff, k, kernel, Tk, &kp, &kt, prof, false, !p.use_previous);
+        if (st) return st;
+        launches += c->info.jacobi_launches;
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        c->info.iterations_done = k;
+    } else {
+        c->info.iterations_done = hit >= 0 ? hit + 1 : iters;
+    }
+    c->info.last_eps = last;
+    c->info.jacobi_launches = launches;
+    prof.collect();
+    return HSFLOW_OK;
+}
+
+// EPS without a usable sweep budget (CV_TERMCRIT_EPS alone): Eps_k = max |u_k - u_{k-1}|, |v_k - v_{k-1}|
+// is produced per sweep by the kernel; the host looks at it after every chunk and, if the
+// threshold was crossed inside the chunk, replays the chunk up to that sweep (its input buffer
+// is still intact), which reproduces the oracle's stopping sweep exactly.
+int solve_eps_chunks(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Profiler &prof)
+{
+    const float coeff = S.coeff;
+    const int kernel = S.kernel, T = S.T;
+    const bool multi = S.multi;
+    const JPlan &plan = S.plan;
+    int st = HSFLOW_OK;
+    const long long budget = S.budget;
+    const bool use_iter = S.use_iter;
+    if (!p.use_previous) {
+        c->cur = 0;
+        HS_HIP(c, hipMemsetAsync(c->dU[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+        HS_HIP(c, hipMemsetAsync(c->dV[0], 0, (size_t)c->plane * c->N * sizeof(float), c->stream));
+    }
+    if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV)) {
+        prof.begin(0);
+        HS_HIP(c, launch_deriv(c));
+        prof.end();
+    }
+    c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CV;
+    long long done = 0;
+    int launches = 0;
+    float last = 0.f;
+    bool stop = false;
+    while (!stop) {
+        const int chunk = (int)std::min<long long>(T, budget - done);
+        JPlan cp = plan;
+        if (multi && chunk != T && !make_jplan(c, kernel, chunk, p, cp))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+        const int a = c->cur, b = a ^ 1;
+        const int n = multi ? chunk : 1;
+        if ((st = eps_prepare(c, n, multi ? plan_eps_stride(kernel, cp) : 1))) return st;
+        c->epsPtr = c->dEpsTiles;
+        prof.begin(1);
+        if (!multi)
+            HS_HIP(c, launch_simple(c, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+        else
+            HS_HIP(c, launch_j(c, cp, true, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+        prof.end();
+        launches++;
+        std::vector<unsigned> heps;
+        if ((st = eps_collect(c, n, heps))) return st;
+        int hit = -1;
+        for (int s = 0; s < n; s++) {
+            float e;
+            std::memcpy(&e, &heps[(size_t)s], sizeof(float));
+            last = e;
+            if ((double)e < p.epsilon) { hit = s; break; }
+        }
+        if (hit >= 0 && hit < n - 1) { // crossed inside the chunk: redo exactly hit+1 sweeps
+            JPlan rp;
+            if (!make_jplan(c, kernel, hit + 1, p, rp))
+                return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the replay");
+            prof.begin(1);
+            HS_HIP(c, launch_j(c, rp, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff));
+            prof.end();
+            launches++;
+            done += hit + 1;
+            stop = true;
+        } else {
+            done += n;
+            if (hit >= 0) stop = true;
+        }
+        c->cur = b;
+        if (use_iter && p.max_iter > 0 && done >= budget) stop = true;
+    }
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    c->info.iterations_done = (int)done;
+    c->info.last_eps = last;
+    c->info.jacobi_launches = launches;
+    prof.collect();
+    return HSFLOW_OK;
+}
+
+int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve comes first
+    if (!pp || pp->struct_size != sizeof(hsflow_params))
+        return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
+    const hsflow_params &p = *pp;
+    if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
+    if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) return solve_classic(c, p, async);
+    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
+    const bool use_iter = (p.term_type & HSFLOW_TERM_ITER) != 0, use_eps = (p.term_type & HSFLOW_TERM_EPS) != 0;
+    if (!use_iter && !use_eps) return fail(c, HSFLOW_E_ARG, "term_type must include ITER and/or EPS");
+    if (use_iter && p.max_iter <= 0 && !use_eps)
+        return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+    if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
+    if (async && p.profile) return fail(c, HSFLOW_E_ARG, "solve_async does not support profiling");
+    c->info.eps_rerun = 0;
+
+    const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
+    // AUTO: the register-strip kernel; below ~1.5 Mpixel per context its folded form (128-column strips:
+    // twice the tiles across, so small frames reach more CUs -- measured 5-25 % faster from 160x120 to
+    // 1600x900 at 100 sweeps, tools/crossover.py).
+    const bool small_frame = (long long)c->W * c->H * c->N <= 1500000LL;
+    const int kernel = p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel : (small_frame ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
+    if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP &&
+        kernel != HSFLOW_KERNEL_FOLD)
+        return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
+    const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
+    if (async && use_eps && !(use_iter && p.max_iter > 0 && p.max_iter <= (1 << 16) &&
+                              (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact))
+        return fail(c, HSFLOW_E_ARG, "solve_async with EPS termination needs ITER|EPS with a sweep budget and the strip / fold kernel "
+                                     "(ITER-only termination works with every kernel)");
+    // With ITER the sweep budget is max_iter (a budget <= 0 with EPS never triggers ITER);
+    // EPS-only runs use chunks until Eps < epsilon.
+    const long long budget = (use_iter && p.max_iter > 0) ? p.max_iter : (1LL << 40);
+
+    int T = 1;
+    JPlan plan;
+    if (multi) {
+        const int horizon = budget > (1 << 30) ? 64 : (int)budget; // EPS-only runs: plan for chunks
+        if (p.fuse_steps > 0) T = std::min(p.fuse_steps, kMaxFuse);
+        else if (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)
+            T = (use_eps && !(use_iter && p.max_iter > 0)) ? std::min(8, horizon)
+                                                          : pick_strip_T(c, horizon, p, kernel == HSFLOW_KERNEL_FOLD);
+        else T = pick_T(horizon, 0);
+        if (budget < T) T = (int)budget;
+        if (!make_jplan(c, kernel, T, p, plan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the requested tile/threads/rows/fuse_steps");
+        plan_to_info(c, plan);
+    } else {
+        c->info.fuse_steps = 1; c->info.tile_w = c->info.tile_h = 0; c->info.threads = 256;
+        c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
+    }
+    c->info.kernel = kernel;
+    c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;
+    c->info.last_eps = 0.f;
+    Profiler prof{c, p.profile != 0};
+
+    SolveSetup S{coeff, kernel, multi, use_iter, use_eps, budget, T, plan};
+    if (!use_eps) return solve_fixed(c, p, S, prof, async);
+    constexpr long long kSpecMax = 1 << 16; // speculative ITER|EPS: the whole budget in one go
+    if (use_iter && p.max_iter > 0 && budget <= kSpecMax) return solve_iter_eps(c, p, S, prof, async);
+    return solve_eps_chunks(c, p, S, prof);
+}
+
+int copy_frame_in(hsflow_ctx *c, uint8_t *dst, const void *src, size_t stride, hipMemcpyKind kind, bool sync)
+{
+    if (sync) HS_HIP(c, hipMemcpy2D(dst, c->P, src, stride, c->W, c->H, kind));
+    else HS_HIP(c, hipMemcpy2DAsync(dst, c->P, src, stride, c->W, c->H, kind, c->stream));
+    return HSFLOW_OK;
+}
+
+} // namespace
