@@ -435,661 +435,11 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// a2, form 3: T Jacobi sweeps per launch on register-resident strips ("strip").
-//
-// A workgroup of NW wavefronts owns a region of 256 columns x (NW*R) rows.  Wavefront w holds rows
-// [w*R, (w+1)*R) entirely in VGPRs: lane l owns the 4 pixels of columns 4l..4l+3 in each of its R
-// rows (u, v and the four coefficients).  Per sweep:
-//   * left/right neighbours come from lanes l-1 / l+1 by DPP wave shifts (the wavefront spans the
-//     whole region width, so there is no seam: lanes 0 and 63 sit on the region edge);
-//   * up/down neighbours inside the strip are the lane's own registers;
-//   * only the strip's first and last row go through LDS (double-buffered, ONE barrier per sweep)
-//     to reach the wavefronts above and below.
-// LDS traffic per sweep is 2 of R rows instead of all of them and nothing is re-read, so the sweep
-// is bound by VALU issue (~13 flops per pixel) rather than by LDS or barriers.
-//
-// Image borders cost nothing inside the sweep loop: Jacobi with a replicate border is exactly
-// Jacobi on the EVEN REFLECTION of the image (u(-1-k) = u(k), same for the coefficients): the
-// mirrored pixel sees the mirrored neighbour set, so the extension stays a reflection sweep after
-// sweep, bit for bit, and pixel 0's left neighbour u(-1) equals u(0) -- the replicate rule.  So the
-// halo outside the image is simply LOADED from mirrored coordinates and then swept like any other
-// pixel; no select, no ghost copy.
-// ------------------------------------------------------------------------------------------
-struct StripGeom {
-    int W, H, P;
-    long long plane;
-    int T, HX;          // sweeps per launch; horizontal halo (multiple of 4, >= T)
-    int CW, CH;         // core = (256 - 2*HX) x (NW*R - 2*T)
-    int NW;             // wavefronts per workgroup
-    int tiles_x, tiles_y;
-    int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
-};
+} // namespace hsk
 
-// index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
-__device__ __forceinline__ int mirror_index(int i, int n)
-{
-    if (i < 0) i = -1 - i;            // one bounce covers every image at least as large as the halo
-    if (i >= n) i = 2 * n - 1 - i;
-    if ((unsigned)i >= (unsigned)n) { // tiny image: general even-periodic extension
-        const int p = 2 * n;
-        int m = i % p;
-        if (m < 0) m += p;
-        i = m < n ? m : p - 1 - m;
-    }
-    return i;
-}
+#include "hs_kernels_strip.hip.h"
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
-
-// One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs, so that every
-// arithmetic step except the four side-neighbour additions is a packed (2 pixels per
-// instruction) v_pk_add/mul/fma_f32.  Summation order = the canonical one of update_cv<>:
-//   p0: ((p1 + (U+D)) + left)   p1: ((p0 + (U+D)) + p2)   p2: ((p3 + (U+D)) + p1)   p3: ((p2 + (U+D)) + right)
-struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
-
-__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const f2 upuP, const f2 upuQ,
-                                                 const f2 upvP, const f2 upvQ, const f2 dnuP, const f2 dnuQ,
-                                                 const f2 dnvP, const f2 dnvQ, const RowCoef &c)
-{
-    // u plane
-    f2 tP = f2_swap(uP) + (upuP + dnuP);
-    f2 tQ = f2_swap(uQ) + (upuQ + dnuQ);
-    tP.x += wave_from_prev_lane(uQ.y);
-    tP.y += uQ.x;
-    tQ.x += uP.y;
-    tQ.y += wave_from_next_lane(uP.x);
-    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f;
-    // v plane
-    f2 sP = f2_swap(vP) + (upvP + dnvP);
-    f2 sQ = f2_swap(vQ) + (upvQ + dnvQ);
-    sP.x += wave_from_prev_lane(vQ.y);
-    sP.y += vQ.x;
-    sQ.x += vP.y;
-    sQ.y += wave_from_next_lane(vP.x);
-    const f2 vbP = sP * 0.25f, vbQ = sQ * 0.25f;
-    // update
-    const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
-    const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
-    uP = f2_fma(-c.alP, qP, ubP);
-    vP = f2_fma(-c.beP, qP, vbP);
-    uQ = f2_fma(-c.alQ, qQ, ubQ);
-    vQ = f2_fma(-c.beQ, qQ, vbQ);
-}
-
-template <int R, int NTMAX, int EPS>
-__global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
-                                                        const float *__restrict__ u_in,
-                                                        const float *__restrict__ v_in,
-                                                        float *__restrict__ u_out,
-                                                        float *__restrict__ v_out, const StripGeom g,
-                                                        const float ilambda,
-                                                        unsigned *__restrict__ eps_out, const int eps_stride,
-                                                        unsigned long long *__restrict__ stamps,
-                                                        const float eps_thr)
-{
-    // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
-    // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
-    // EPS == 2 ("witness"): the cheap way to PROVE that no sweep of this launch had Eps < epsilon.
-    // At the end of a sweep a wavefront whose first row is a core row asks "did u change by >= eps_thr
-    // at column x0 of any lane of that row?" -- old and new value come back from the two exchange
-    // buffers, so nothing is kept in registers for it -- and counts the
-    // per-sweep answers in an SGPR.  Each |change| is a lower bound of that sweep's Eps, so a
-    // wavefront that answered yes in EVERY sweep proves Eps_k >= eps_thr for all k of the launch;
-    // eps_out[workgroup] = +inf if any wavefront of the workgroup did, else 0.
-    // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
-    // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
-    // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hs_runtime.hip.h).
-    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2][NW][4][64], then 32 floats for Eps
-    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
-    if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NW = g.NW;
-    float *eps_lds = (float *)(ex + (size_t)2 * NW * 4 * 64);
-    // Synchronisation between sweeps: ONE workgroup barrier per sweep.  Experiment kept behind
-    // HS_STRIP_P2P (default 0, measured SLOWER: 0.220 vs 0.200 ms at 1080p / 100 sweeps): a wavefront only
-    // depends on the strips directly above and below, so each wavefront raises a counter in LDS once its
-    // edge rows of a sweep are published and waits only for its two neighbours' counters.  LDS executes a
-    // wavefront's requests in order, so "counter >= s" implies that neighbour's rows for sweep s are in
-    // place AND that its reads of the buffer about to be overwritten are done (they precede its publish).
-#ifndef HS_STRIP_P2P
-#define HS_STRIP_P2P 0
-#endif
-    constexpr bool P2P = HS_STRIP_P2P && EPS != 1; // the per-sweep Eps fold of EPS == 1 relies on the barrier
-    volatile unsigned *flags = (volatile unsigned *)(eps_lds + 32); // [NW] sweeps published so far
-    const int tpp = g.tiles_x * g.tiles_y;
-    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-    const int pair = tile / tpp;
-    const int t2 = tile - pair * tpp;
-    const int by = t2 / g.tiles_x, bx = t2 - by * g.tiles_x;
-    const int x0 = bx * g.CW - g.HX + 4 * lane;
-    const int y0 = by * g.CH - g.T + w * R;
-    const long long base = (long long)pair * g.plane;
-    const bool xin = (x0 >= 0) && (x0 + 3 < g.W); // the whole group lies inside the image
-
-    f2 uP[R], uQ[R], vP[R], vQ[R];
-    RowCoef cf[R];
-    float4 lu[R], lv[R];
-    uint4 lc[R];
-    // Workgroup-uniform: does the region (core + halo) stick out of the image on the left or right?
-    // Tiles that do not (the vast majority) load with plain aligned 16-byte accesses only.
-    const int rx0 = bx * g.CW - g.HX;
-    const bool xedge = !(rx0 >= 0 && rx0 + 256 <= g.W);
-    if (!xedge) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const long long off = base + (long long)mirror_index(y0 + r, g.H) * g.P + x0;
-            lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!g.zero_in) {
-                lu[r] = *(const float4 *)(u_in + off);
-                lv[r] = *(const float4 *)(v_in + off);
-            }
-            lc[r] = *(const uint4 *)(coef + off);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const long long row = base + (long long)mirror_index(y0 + r, g.H) * g.P;
-            // A group that lies completely outside the image on the left mirrors onto an aligned
-            // group read backwards (columns -1-k <-> k); the same holds on the right when W % 4 == 0.
-            // Those lanes keep the 16-byte loads (from the mirrored address, components reversed).
-            // Only groups that straddle column W-1 or sit right of it when W % 4 != 0 (and images
-            // narrower than the halo) fall back to four reflected scalar loads per plane.
-            int xg = x0;
-            bool rev = false, slow = false;
-            if (!xin) {
-                if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; rev = true; }
-                else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
-                else { xg = 0; slow = true; }
-            }
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (!g.zero_in) {
-                a = *(const float4 *)(u_in + row + xg);
-                b = *(const float4 *)(v_in + row + xg);
-            }
-            uint4 c = *(const uint4 *)(coef + row + xg);
-            if (rev) {
-                a = make_float4(a.w, a.z, a.y, a.x);
-                b = make_float4(b.w, b.z, b.y, b.x);
-                c = make_uint4(c.w, c.z, c.y, c.x);
-            }
-            if (slow) { // volatile keeps this a separate, rarely taken path
-                const volatile float *uv = u_in + row, *vv = v_in + row;
-                const volatile uint32_t *cv = coef + row;
-                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
-                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-                if (!g.zero_in) {
-                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
-                }
-                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
-            }
-            lu[r] = a; lv[r] = b; lc[r] = c;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const float4 lu_ = lu[r], lv_ = lv[r];
-        const uint4 cw = lc[r];
-        uP[r] = f2{lu_.x, lu_.y}; uQ[r] = f2{lu_.z, lu_.w};
-        vP[r] = f2{lv_.x, lv_.y}; vQ[r] = f2{lv_.z, lv_.w};
-        float al[4], be[4], ga[4];
-        const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
-        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
-        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
-    }
-    // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
-    unsigned rowcore = 0;
-    int rdist[R]; // distance of each row from the core rows (0 inside): wave-uniform
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int j = w * R + r, y = y0 + r;
-        if (j >= g.T && j < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
-        rdist[r] = j < g.T ? g.T - j : (j >= g.T + g.CH ? j - (g.T + g.CH - 1) : 0);
-    }
-    const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
-    const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
-
-    // One row update.  up*/dn* are OLD neighbour rows; the new row replaces uP[r].. in place.
-    // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
-    // sweeps skip it (wave-uniform branch), which trims the redundant halo work by about half.
-#ifdef HS_DIAG_NO_COMPUTE /* diagnostic build only: wrong results, times the exchange alone */
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF) do { uP[r] += UUP + DUP; } while (0)
-#else
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF)                                      \
-    do {                                                                                           \
-        if (rdist[r] <= g.T - 1 - s) {                                                             \
-            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
-            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF);    \
-            if (EPS) {                                                                             \
-                if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
-                    if (EPS == 1) {                                                                \
-                        const f2 dUP = ouP - uP[r], dUQ = ouQ - uQ[r], dVP = ovP - vP[r], dVQ = ovQ - vQ[r]; \
-                        if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
-                            e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dUQ.x)), fabsf(dUQ.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                       \
-                        } else {                                                                   \
-                            e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                       \
-                            if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));          \
-                            if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));          \
-                            if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));          \
-                        }                                                                          \
-                    }                                                                              \
-                }                                                                                  \
-            }                                                                                      \
-        }                                                                                          \
-        /* (no scheduling barrier between rows: letting the scheduler overlap them is 1.7 % faster    \
-           and, with this compiler, also spills less in the Eps variants) */                      \
-    } while (0)
-#endif
-#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS) /* diagnostic builds only: wrong results */
-#define HS_PUBLISH(buf) do { } while (0)
-#else
-#define HS_PUBLISH(buf)                                                                            \
-    do {                                                                                           \
-        float4 *exw = ex + ((size_t)((buf) * NW + w) * 4) * 64 + lane;                             \
-        exw[0] = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y);                                  \
-        exw[64] = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);                                 \
-        exw[128] = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y);                \
-        exw[192] = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);                \
-    } while (0)
-#endif
-
-#define HS_RAISE(n)                                                                                \
-    do {                                                                                           \
-        if (P2P) {                                                                                 \
-            asm volatile("" ::: "memory"); /* the rows first (LDS keeps a wavefront's order) */    \
-            if (lane == 0) flags[w] = (unsigned)(n);                                               \
-        }                                                                                          \
-    } while (0)
-
-    // Exchange slots: ex[buf][wave][0..3][lane] = {first row u, first row v, last row u, last row v}.
-    // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
-    // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
-    // LDS writes drain while the interior rows are being computed.
-    HS_PUBLISH(0);
-    if (P2P && threadIdx.x < NW) flags[threadIdx.x] = 0;
-    __syncthreads();
-    if (stamps) st1 = __builtin_amdgcn_s_memtime();
-    const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
-    const int wd = w < NW - 1 ? w + 1 : w, sd = w < NW - 1 ? 0 : 2; // strip below: its first row
-    // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
-    int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
-                    // loop-carried flag makes the register allocator spill inside the loop)
-#pragma unroll 1
-    for (int s = 0; s < g.T; s++) {
-#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
-        const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
-#else
-        const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
-        const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
-        float4 hu4, hv4, du4, dv4;
-        if (P2P) {
-            // counters first, rows right behind them in the same batch of LDS reads: if the counters
-            // (read earlier) say "published", the rows (read later) are the published ones; otherwise
-            // the batch is simply repeated
-            for (;;) {
-                asm volatile("" ::: "memory");
-                const unsigned fa = flags[wu], fb = flags[wd];
-                hu4 = eu[0]; hv4 = eu[64];   // old row above the strip
-                du4 = ed[0]; dv4 = ed[64];   // old row below the strip
-                if (fa >= (unsigned)s && fb >= (unsigned)s) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } else {
-            hu4 = eu[0]; hv4 = eu[64];
-            du4 = ed[0]; dv4 = ed[64];
-        }
-#endif
-        const f2 huP = f2{hu4.x, hu4.y}, huQ = f2{hu4.z, hu4.w}, hvP = f2{hv4.x, hv4.y}, hvQ = f2{hv4.z, hv4.w};
-        const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
-        float e = 0.f;
-        if (R == 1) {
-            HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ, cf[0]);
-        } else {
-            constexpr int R1 = R > 1 ? 1 : 0, RM = R > 2 ? R - 2 : 0;
-            const f2 o0uP = uP[0], o0uQ = uQ[0], o0vP = vP[0], o0vQ = vQ[0];                 // old first row
-            const f2 oNuP = uP[R - 1], oNuQ = uQ[R - 1], oNvP = vP[R - 1], oNvQ = vQ[R - 1]; // old last row
-            HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
-            if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
-            else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
-            if (EPS == 2 || s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
-            f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
-#pragma unroll
-            for (int r = 1; r < R - 1; r++) {
-                const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
-                const int rn = r + 1 < R ? r + 1 : r;
-                if (r + 1 == R - 1) HS_ROW(r, puP, puQ, pvP, pvQ, oNuP, oNuQ, oNvP, oNvQ, cf[r]);
-                else HS_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn], cf[r]);
-                puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
-            }
-        }
-        if (R == 1 && (EPS == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
-        if (EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
-            e = wave_max_nonneg(lanecore ? e : 0.f);
-            if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
-            if (s > 0 && w == 0) {
-                float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
-                x = wave_max_nonneg(x);
-                if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
-            }
-        }
-        if (EPS == 2 && (rowcore & 1u)) {
-            // witness, read back from the exchange buffers at the end of the sweep (no register is kept
-            // for it): slot 0 of this wavefront holds its first row of u, new in buffer (s+1)&1 and old
-            // in buffer s&1; component x is column x0, an image column wherever lanecore holds
-            const float nu = *(const float *)(ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane);
-            const float ou = *(const float *)(ex + ((size_t)((s & 1) * NW + w) * 4) * 64 + lane);
-            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
-        }
-#if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
-        if (!P2P && s + 1 < g.T) __syncthreads();
-#endif
-    }
-    if (EPS == 1) {
-        __syncthreads();
-        if (w == 0) {
-            float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
-            x = wave_max_nonneg(x);
-            if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
-        }
-    }
-    if (EPS == 2) {
-        if (lane == 0) eps_lds[w] = (seen_n == g.T && (rowcore & 1u)) ? __builtin_inff() : 0.f;
-        __syncthreads();
-        if (w == 0) {
-            const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
-        }
-    }
-#undef HS_ROW
-#undef HS_PUBLISH
-#undef HS_RAISE
-    if (stamps) st2 = __builtin_amdgcn_s_memtime();
-
-    if (lanecore) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if ((rowcore >> r) & 1u) {
-                const long long off = base + (long long)(y0 + r) * g.P + x0;
-#if defined(HS_EXP_NT_STORE) /* experiment (slower): non-temporal stores */
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, (v4f *)(u_out + off));
-                __builtin_nontemporal_store(v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y}, (v4f *)(v_out + off));
-#elif defined(HS_EXP_SC1_STORE) /* experiment: agent-scope write-through stores (nothing dirty at kernel end) */
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f su_ = v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, sv_ = v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(u_out + off), "v"(su_) : "memory");
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(v_out + off), "v"(sv_) : "memory");
-#else
-                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
-#endif
-            }
-        }
-    }
-    if (stamps && threadIdx.x == 0) {
-        __builtin_amdgcn_s_waitcnt(0); // stores issued and acknowledged
-        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
-        o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
-        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); // XCC_ID
-        o[7] = (unsigned long long)tile;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// a2, form 4: "folded" strips.  Same register-resident scheme as k_jacobi_strip, but one wavefront
-// holds TWO vertically adjacent strips of 128 columns: lanes 0-31 the upper one (rows top->bottom
-// in registers 0..R-1), lanes 32-63 the lower one in MIRRORED order (register r = block row
-// 2R-1-r).  Both halves then have their wave-internal boundary at register row R-1 and their
-// outer edge at register row 0, so
-//   * the inner boundary is exchanged inside the wavefront (v_permlane32_swap, no LDS),
-//   * each wavefront publishes ONE row per half through LDS (2 ds_write_b128 + 2 ds_read_b128 per
-//     sweep instead of 4 + 4) -- the LDS edge-row exchange is what bounds the strip kernel,
-//   * no per-half selects are needed: the update is symmetric in up/down, so the lower half simply
-//     walks its rows in the opposite direction.
-// The DPP wave shifts cross the lane 31/32 seam, which is harmless: lanes 31 and 32 sit on the
-// region's right / left edge (junk the validity argument tolerates).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_xor32(float x, bool lower)
-{
-    // value of the same register in lane (l ^ 32)
-    const unsigned b = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false); // r[0] = {lo, lo}, r[1] = {hi, hi}
-    return __uint_as_float(lower ? r[0] : r[1]);
-}
-
-template <int R, int NTMAX, int EPS> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
-__global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
-                                                       const float *__restrict__ u_in,
-                                                       const float *__restrict__ v_in,
-                                                       float *__restrict__ u_out,
-                                                       float *__restrict__ v_out, const StripGeom g,
-                                                       const float ilambda,
-                                                       unsigned *__restrict__ eps_out, const int eps_stride,
-                                                       unsigned long long *__restrict__ stamps,
-                                                       const float eps_thr)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
-    unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
-    if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-    const int lane = threadIdx.x & 63, hl = lane & 31;
-    const bool lower = lane >= 32;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NW = g.NW;
-    float *eps_lds = (float *)(ex + (size_t)2 * NW * 2 * 2 * 32);
-    const int tpp = g.tiles_x * g.tiles_y;
-    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-    const int pair = tile / tpp;
-    const int t2 = tile - pair * tpp;
-    const int by = t2 / g.tiles_x, bx = t2 - by * g.tiles_x;
-    const int rx0 = bx * g.CW - g.HX;
-    const int x0 = rx0 + 4 * hl;
-    const int yb = by * g.CH - g.T + w * 2 * R; // first block row of this wavefront
-    const long long base = (long long)pair * g.plane;
-    const bool xin = (x0 >= 0) && (x0 + 3 < g.W);
-
-    f2 uP[R], uQ[R], vP[R], vQ[R];
-    RowCoef cf[R];
-    float4 lu[R], lv[R];
-    uint4 lc[R];
-    const bool side = !(rx0 >= 0 && rx0 + 128 <= g.W); // workgroup-uniform
-    int xg = x0;
-    bool rev = false, slow = false;
-    if (side && !xin) { // see k_jacobi_strip: mirrored aligned group, or the general scalar path
-        if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; rev = true; }
-        else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
-        else { xg = 0; slow = true; }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int y = yb + (lower ? 2 * R - 1 - r : r);
-        const long long row = base + (long long)mirror_index(y, g.H) * g.P;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (!g.zero_in) {
-            a = *(const float4 *)(u_in + row + xg);
-            b = *(const float4 *)(v_in + row + xg);
-        }
-        uint4 c = *(const uint4 *)(coef + row + xg);
-        if (side) {
-            if (rev) {
-                a = make_float4(a.w, a.z, a.y, a.x);
-                b = make_float4(b.w, b.z, b.y, b.x);
-                c = make_uint4(c.w, c.z, c.y, c.x);
-            }
-            if (slow) { // volatile keeps this a separate, rarely taken path
-                const volatile float *uv = u_in + row, *vv = v_in + row;
-                const volatile uint32_t *cv = coef + row;
-                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
-                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-                if (!g.zero_in) {
-                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
-                }
-                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
-            }
-        }
-        lu[r] = a; lv[r] = b; lc[r] = c;
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        uP[r] = f2{lu[r].x, lu[r].y}; uQ[r] = f2{lu[r].z, lu[r].w};
-        vP[r] = f2{lv[r].x, lv[r].y}; vQ[r] = f2{lv[r].z, lv[r].w};
-        float al[4], be[4], ga[4];
-        const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
-#pragma unroll
-        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
-        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
-        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
-    }
-    // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
-    unsigned rowcore = 0;
-    int rdist[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int jl = w * 2 * R + (lower ? 2 * R - 1 - r : r), y = yb + (lower ? 2 * R - 1 - r : r);
-        if (jl >= g.T && jl < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
-        const int ju = w * 2 * R + r, jd = w * 2 * R + 2 * R - 1 - r;
-        const int du = ju < g.T ? g.T - ju : (ju >= g.T + g.CH ? ju - (g.T + g.CH - 1) : 0);
-        const int dd = jd < g.T ? g.T - jd : (jd >= g.T + g.CH ? jd - (g.T + g.CH - 1) : 0);
-        rdist[r] = du < dd ? du : dd; // the row is computed while either half still needs it
-    }
-    const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * hl >= g.HX) && (4 * hl < g.HX + g.CW);
-    const int pr = g.W - 1 - x0;
-
-#define HF_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
-    do {                                                                                           \
-        if (rdist[r] <= g.T - 1 - s) {                                                             \
-            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
-            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
-            if (EPS == 1) {                                                                        \
-                if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
-                    e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
-                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
-                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ouQ.x - uQ[r].x), fabsf(ovQ.x - vQ[r].x))); \
-                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ouQ.y - uQ[r].y), fabsf(ovQ.y - vQ[r].y))); \
-                }                                                                                  \
-            }                                                                                      \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    } while (0)
-    // slot of (buffer, wavefront, half): two planes of 32 float4
-#define HF_SLOT(buf, ww, hh) (ex + ((size_t)(((buf) * NW + (ww)) * 2 + (hh)) * 2) * 32)
-#define HF_PUBLISH(buf)                                                                            \
-    do {                                                                                           \
-        float4 *exw = HF_SLOT(buf, w, lower ? 1 : 0) + hl;                                         \
-        exw[0] = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y);                                  \
-        exw[32] = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);                                 \
-    } while (0)
-
-    HF_PUBLISH(0);
-    __syncthreads();
-    if (stamps) st1 = __builtin_amdgcn_s_memtime();
-    // outer neighbour: upper half <- bottom row of the wavefront above (its half 1),
-    //                  lower half <- top row of the wavefront below (its half 0);
-    // at the region edge the wavefront's own slot stands in (junk the validity argument tolerates)
-    const int wo = lower ? (w < NW - 1 ? w + 1 : w) : (w > 0 ? w - 1 : w);
-    const int ho = lower ? (w < NW - 1 ? 0 : 1) : (w > 0 ? 1 : 0);
-    int seen_n = 0; // EPS == 2: sweeps in which some lane of this wavefront saw a change >= eps_thr
-#pragma unroll 1
-    for (int s = 0; s < g.T; s++) {
-        const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
-        const float4 h4u = eo[0], h4v = eo[32];
-        const f2 ouP_ = f2{h4u.x, h4u.y}, ouQ_ = f2{h4u.z, h4u.w}, ovP_ = f2{h4v.x, h4v.y}, ovQ_ = f2{h4v.z, h4v.w};
-        // inner neighbour: the other half's register row R-1 (old values), in-register exchange
-        const f2 iuP = f2{lane_xor32(uP[R - 1].x, lower), lane_xor32(uP[R - 1].y, lower)};
-        const f2 iuQ = f2{lane_xor32(uQ[R - 1].x, lower), lane_xor32(uQ[R - 1].y, lower)};
-        const f2 ivP = f2{lane_xor32(vP[R - 1].x, lower), lane_xor32(vP[R - 1].y, lower)};
-        const f2 ivQ = f2{lane_xor32(vQ[R - 1].x, lower), lane_xor32(vQ[R - 1].y, lower)};
-        float e = 0.f;
-        // register row 0 (the published outer edge) first, so that its LDS write drains under the
-        // other rows; then rows 1..R-1 walking towards the inner boundary, keeping one old row
-        f2 puP = uP[0], puQ = uQ[0], pvP = vP[0], pvQ = vQ[0];
-        if (R == 1) {
-            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, iuP, iuQ, ivP, ivQ);
-        } else {
-            constexpr int R1 = R > 1 ? 1 : 0;
-            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
-        }
-        if (EPS == 2 || s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
-#pragma unroll
-        for (int r = 1; r < R; r++) {
-            const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
-            const int rn = r + 1 < R ? r + 1 : r;
-            if (r == R - 1) HF_ROW(r, puP, puQ, pvP, pvQ, iuP, iuQ, ivP, ivQ);
-            else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
-            puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
-        }
-        if (EPS == 2) {
-            // witness (k_jacobi_strip explains it): old and new value of the published row -- register
-            // row 0 of each half -- at column x0 come back from the two exchange buffers
-            const float nu = *(const float *)(HF_SLOT((s + 1) & 1, w, lower ? 1 : 0) + hl);
-            const float ou = *(const float *)(HF_SLOT(s & 1, w, lower ? 1 : 0) + hl);
-            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
-        }
-        if (EPS == 1) {
-            e = wave_max(e);
-            if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
-            if (s > 0 && w == 0) {
-                float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
-                x = wave_max(x);
-                if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
-            }
-        }
-        if (s + 1 < g.T) __syncthreads();
-    }
-    if (EPS == 1) {
-        __syncthreads();
-        if (w == 0) {
-            float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
-            x = wave_max(x);
-            if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
-        }
-    }
-    if (EPS == 2) {
-        if (lane == 0) eps_lds[w] = seen_n == g.T ? __builtin_inff() : 0.f;
-        __syncthreads();
-        if (w == 0) {
-            const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
-        }
-    }
-#undef HF_ROW
-#undef HF_PUBLISH
-#undef HF_SLOT
-    if (stamps) st2 = __builtin_amdgcn_s_memtime();
-
-    if (lanecore) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if ((rowcore >> r) & 1u) {
-                const int y = yb + (lower ? 2 * R - 1 - r : r);
-                const long long off = base + (long long)y * g.P + x0;
-                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
-            }
-        }
-    }
-    if (stamps && threadIdx.x == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
-        o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
-        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
-        o[7] = (unsigned long long)tile;
-    }
-}
+namespace hsk {
 
 // Eps of every sweep = maximum over that sweep's row of per-workgroup values (bit patterns of
 // non-negative floats order like unsigned integers).  One workgroup per sweep.
