@@ -237,6 +237,12 @@ int hsflow_pipeline_drain(hsflow_pipeline *pl);                 /* wait for ever
 int hsflow_pipeline_depth(hsflow_pipeline *pl);
 const char *hsflow_pipeline_last_error(hsflow_pipeline *pl);    /* pl may be NULL: create() error */
 
+/* Planner introspection, no device needed: the kernel, sweeps per launch, tile shape, workgroup size,
+ * tiles per launch, LDS bytes and launch count hsflow_solve would use for a context of this size with
+ * these parameters (same code path as the solver's own planning; text of a refusal in
+ * hsflow_last_error(NULL)).  info->struct_size must be set. */
+int hsflow_plan_query(int width, int height, int n_pairs, const hsflow_params *params, hsflow_info *info);
+
 /* --- one-shot ------------------------------------------------------------------------------ */
 
 /* Same argument list as OpenCV's inner routine behind cvCalcOpticalFlowHS: strides in bytes,

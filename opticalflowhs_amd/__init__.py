@@ -7,10 +7,10 @@ no CPU fallback: importing it without libhsflow.so raises.
 from . import _lib
 from ._lib import (HsflowError, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED, MODE_CV,
                    TERM_EPS, TERM_ITER)
-from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, make_params, term_criteria
+from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, make_params, plan_query, term_criteria
 from .pipeline import PairPipeline, pinned_empty
 
-__all__ = ["HSFlow", "PairPipeline", "pinned_empty", "make_params", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
+__all__ = ["HSFlow", "PairPipeline", "pinned_empty", "make_params", "plan_query", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
            "TERM_ITER", "TERM_EPS", "MODE_CV", "MODE_CLASSIC", "MODE_CLASSIC_AS_SHIPPED", "KERNEL_AUTO", "KERNEL_SIMPLE",
            "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD"]
 

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "hsflow_version": (_i, []),
     "hsflow_device_count": (_i, [ctypes.POINTER(_i)]),
     "hsflow_release_cached": (None, []),
+    "hsflow_plan_query": (_i, [_i, _i, _i, _pp, ctypes.POINTER(HsflowInfo)]),
     "hsflow_host_alloc": (_i, [ctypes.POINTER(_vp), _sz]),
     "hsflow_host_free": (_i, [_vp]),
     "hsflow_host_register": (_i, [_vp, _sz]),

@@ -492,24 +492,16 @@ int solve_eps_chunks(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S,
     return HSFLOW_OK;
 }
 
-int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
+// CV mode: argument checks, kernel choice (AUTO rule) and launch plan.  Touches no device state, so the
+// planner can also be queried without a GPU (hsflow_plan_query).  Fills c->info's plan fields.
+int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup &S)
 {
-    int st = check_ctx(c, 0);
-    if (st) return st;
-    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve comes first
-    if (!pp || pp->struct_size != sizeof(hsflow_params))
-        return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
-    const hsflow_params &p = *pp;
-    if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
-    if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) return solve_classic(c, p, async);
-    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
     const bool use_iter = (p.term_type & HSFLOW_TERM_ITER) != 0, use_eps = (p.term_type & HSFLOW_TERM_EPS) != 0;
     if (!use_iter && !use_eps) return fail(c, HSFLOW_E_ARG, "term_type must include ITER and/or EPS");
     if (use_iter && p.max_iter <= 0 && !use_eps)
         return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
     if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
     if (async && p.profile) return fail(c, HSFLOW_E_ARG, "solve_async does not support profiling");
-    c->info.eps_rerun = 0;
 
     const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
     // AUTO: the register-strip kernel; below ~1.5 Mpixel per context its folded form (128-column strips:
@@ -547,14 +539,30 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
         c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
     }
     c->info.kernel = kernel;
+    S = SolveSetup{coeff, kernel, multi, use_iter, use_eps, budget, T, plan};
+    return HSFLOW_OK;
+}
+
+int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve comes first
+    if (!pp || pp->struct_size != sizeof(hsflow_params))
+        return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
+    const hsflow_params &p = *pp;
+    if (!c->frames_set) return fail(c, HSFLOW_E_STATE, "frames were not set");
+    if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) return solve_classic(c, p, async);
+    if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
+    c->info.eps_rerun = 0;
+    SolveSetup S;
+    if ((st = prepare_solve(c, p, async, S))) return st;
     c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;
     c->info.last_eps = 0.f;
     Profiler prof{c, p.profile != 0};
-
-    SolveSetup S{coeff, kernel, multi, use_iter, use_eps, budget, T, plan};
-    if (!use_eps) return solve_fixed(c, p, S, prof, async);
+    if (!S.use_eps) return solve_fixed(c, p, S, prof, async);
     constexpr long long kSpecMax = 1 << 16; // speculative ITER|EPS: the whole budget in one go
-    if (use_iter && p.max_iter > 0 && budget <= kSpecMax) return solve_iter_eps(c, p, S, prof, async);
+    if (S.use_iter && p.max_iter > 0 && S.budget <= kSpecMax) return solve_iter_eps(c, p, S, prof, async);
     return solve_eps_chunks(c, p, S, prof);
 }
 

@@ -469,6 +469,47 @@ int hsflow_calc_optical_flow_hs_8u32f(const uint8_t *prev, const uint8_t *curr, 
     return st;
 }
 
+int hsflow_plan_query(int width, int height, int n_pairs, const hsflow_params *pp, hsflow_info *out)
+{
+    if (!pp || pp->struct_size != sizeof(hsflow_params)) return fail(nullptr, HSFLOW_E_ARG, "params null or struct_size mismatch");
+    if (!out || out->struct_size != sizeof(hsflow_info)) return fail(nullptr, HSFLOW_E_ARG, "info null or struct_size mismatch");
+    if (width <= 0 || height <= 0 || n_pairs <= 0) return fail(nullptr, HSFLOW_E_SIZE, "width, height, n_pairs must be positive");
+    if ((long long)round_up(width, 64) * height > (1LL << 30)) return fail(nullptr, HSFLOW_E_SIZE, "plane too large (pitch*height > 2^30)");
+    hsflow_ctx c; // host-side shell only: the planners read sizes, nothing touches a device
+    c.W = width; c.H = height; c.N = n_pairs;
+    c.P = round_up(width, 64);
+    c.plane = (long long)c.P * height;
+    std::memset(&c.info, 0, sizeof(c.info));
+    c.info.struct_size = sizeof(hsflow_info);
+    c.info.width = width; c.info.height = height; c.info.n_pairs = n_pairs; c.info.pitch = c.P;
+    const hsflow_params &p = *pp;
+    int st = HSFLOW_OK;
+    if (p.mode == HSFLOW_MODE_CV) {
+        SolveSetup S;
+        st = prepare_solve(&c, p, false, S);
+        if (!st) {
+            const long long b = S.budget > (1LL << 30) ? 0 : S.budget;
+            c.info.jacobi_launches = S.multi ? (int)((b + S.T - 1) / S.T) : (int)b;
+        }
+    } else if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) {
+        if (p.max_iter <= 0) st = fail(&c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+        else if (p.kernel == HSFLOW_KERNEL_SIMPLE) { c.info.kernel = HSFLOW_KERNEL_SIMPLE; c.info.fuse_steps = 1; c.info.threads = 256; c.info.jacobi_launches = p.max_iter; }
+        else {
+            const int T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
+            FusedPlan plan;
+            if (!make_plan(&c, T, p.tile_w, p.tile_h, p.threads, plan)) st = fail(&c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
+            else {
+                hsflow_info &i = c.info;
+                i.kernel = HSFLOW_KERNEL_FUSED; i.fuse_steps = T; i.tile_w = plan.g.CW; i.tile_h = plan.g.CH; i.threads = plan.NT;
+                i.groups_per_thread = plan.K; i.tiles = plan.tiles; i.lds_bytes = plan.lds_bytes; i.jacobi_launches = (p.max_iter + T - 1) / T;
+            }
+        }
+    } else st = fail(&c, HSFLOW_E_ARG, "unknown mode");
+    if (st) { g_create_error = c.err; return st; }
+    *out = c.info;
+    return HSFLOW_OK;
+}
+
 void hsflow_release_cached(void)
 {
     std::lock_guard<std::mutex> lock(g_oneshot_mutex);

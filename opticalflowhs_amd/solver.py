@@ -199,6 +199,18 @@ class HSFlow(object):
         return {name: getattr(i, name) for name, _ in HsflowInfo._fields_}
 
 
+def plan_query(width, height, n_pairs=1, params=None, **kw):
+    """The launch plan hsflow_solve would use for this size and these parameters (no device needed)."""
+    lib = _lib.load()
+    p = params if params is not None else make_params(**kw)
+    i = HsflowInfo()
+    i.struct_size = ctypes.sizeof(HsflowInfo)
+    st = lib.hsflow_plan_query(int(width), int(height), int(n_pairs), ctypes.byref(p), ctypes.byref(i))
+    if st:
+        raise HsflowError(st, (lib.hsflow_last_error(None) or b"").decode())
+    return {name: getattr(i, name) for name, _ in HsflowInfo._fields_}
+
+
 def calc_optical_flow_hs(prev, curr, use_previous, velx, vely, lam, criteria, device=0, **tuning):
     """cvCalcOpticalFlowHS(prev, curr, use_previous, velx, vely, lambda, criteria) on the GPU.
 
