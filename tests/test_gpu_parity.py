@@ -475,3 +475,17 @@ def test_graph_cache_stays_bounded(hs, oracle, gpu_ok):
                 u, v = ctx.flow()
                 uo, vo = oracle.calc_optical_flow_hs(A, B, lam, 6, term_type=ITER)
                 check("graph_trim_%d" % i, (u, v), (uo, vo))
+
+
+def test_plan_query_agrees_with_what_a_solve_reports(hs, gpu_ok):
+    """hsflow_plan_query (device-free) and the plan a real solve reports are the same code path."""
+    fields = ("kernel", "fuse_steps", "tile_w", "tile_h", "threads", "groups_per_thread", "tiles", "lds_bytes", "jacobi_launches")
+    for (W, H, N, it, kw) in ((300, 200, 1, 37, {}), (1920, 1080, 1, 100, {}), (257, 129, 2, 9, dict(kernel=hs.KERNEL_FUSED)),
+                              (640, 480, 1, 25, dict(kernel=hs.KERNEL_STRIP, fuse_steps=7)), (500, 400, 1, 12, dict(kernel=hs.KERNEL_SIMPLE)),
+                              (320, 240, 1, 20, dict(mode=hs.MODE_CLASSIC, alpha=3.0))):
+        want = hs.plan_query(W, H, N, lam=1.0, max_iter=it, term_type=ITER, **kw)
+        with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+            for i in range(N):
+                ctx.set_frames(*synth.random_pair(W, H, seed=i), pair=i)
+            got = ctx.solve(lam=1.0, max_iter=it, term_type=ITER, **kw)
+        assert {f: got[f] for f in fields} == {f: want[f] for f in fields}, (W, H, N, it, kw)
