@@ -101,7 +101,10 @@ int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t ps, 
     hsflow_pipeline::Slot &s = pl->slots[pl->next % pl->slots.size()];
     int st = finish_slot(pl, s); // the job that used this slot `depth` submissions ago
     if (st) return st;
-    if ((st = hsflow_set_frames_u8_async(s.ctx, 0, prev, ps, curr, cs))) return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_async");
+    if ((st = hsflow_set_frames_u8_async(s.ctx, 0, prev, ps, curr, cs))) {
+        hsflow_synchronize(s.ctx); // one of the two uploads may have been queued already
+        return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_async");
+    }
     if ((st = hsflow_solve_async(s.ctx, params))) {
         hsflow_synchronize(s.ctx); // the uploads were queued: do not leave them reading caller memory
         return ctx_fail(pl, s.ctx, st, "hsflow_solve_async");
