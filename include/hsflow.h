@@ -152,6 +152,12 @@ int hsflow_set_frames_bgr8(hsflow_ctx *ctx, int pair, const uint8_t *prev_bgr, s
 /* Host u8 gray frames, 3x3 box blur (cvSmooth CV_BLUR, replicate border) on the GPU. Synchronous. */
 int hsflow_set_frames_gray8_blur(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
                                  const uint8_t *curr, size_t curr_stride);
+/* Asynchronous forms of the two above: only enqueued on ctx's stream, host buffers owned by the context
+ * until hsflow_synchronize. */
+int hsflow_set_frames_bgr8_async(hsflow_ctx *ctx, int pair, const uint8_t *prev_bgr, size_t prev_stride,
+                                 const uint8_t *curr_bgr, size_t curr_stride, int blur3x3);
+int hsflow_set_frames_gray8_blur_async(hsflow_ctx *ctx, int pair, const uint8_t *prev, size_t prev_stride,
+                                       const uint8_t *curr, size_t curr_stride);
 /* Streaming (camera loop, HSOpticalFlowOpenCL.cpp:810-834): the current frame becomes the
  * previous one on the device and only the new frame is uploaded. */
 int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t next_stride);
@@ -229,6 +235,15 @@ int hsflow_pipeline_destroy(hsflow_pipeline *pl); /* drains first; NULL accepted
 int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t prev_stride,
                            const uint8_t *curr, size_t curr_stride, float *u, size_t u_stride,
                            float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
+/* Same with the frames in another layout; the CPU route's pre-processing (OpticalFlowOpenCV.cpp:17-28)
+ * then runs on the device as part of the pair's queue. */
+#define HSFLOW_FRAMES_GRAY8 0      /* u8 gray, as hsflow_pipeline_submit                      */
+#define HSFLOW_FRAMES_GRAY8_BLUR 1 /* u8 gray, 3x3 box blur on the device (cvSmooth CV_BLUR)  */
+#define HSFLOW_FRAMES_BGR8 2       /* 8-bit BGR (3 bytes / pixel): BGR->gray on the device    */
+#define HSFLOW_FRAMES_BGR8_BLUR 3  /* BGR->gray and blur: what runFromImg does before solving */
+int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *prev, size_t prev_stride,
+                              const uint8_t *curr, size_t curr_stride, float *u, size_t u_stride,
+                              float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
 int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket); /* u, v of that pair are complete */
 /* wait(ticket) + iterations_done, last_eps, eps_rerun ... of that pair; HSFLOW_E_STATE once a later
  * pair has finished on the same slot (ask before submitting `depth` more pairs). */

@@ -14,6 +14,7 @@ OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
 TERM_ITER, TERM_EPS = 1, 2
 MODE_CV, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED = 0, 1, 2
 KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP, KERNEL_FOLD = 0, 1, 2, 3, 4
+FRAMES_GRAY8, FRAMES_GRAY8_BLUR, FRAMES_BGR8, FRAMES_BGR8_BLUR = 0, 1, 2, 3
 
 
 class HsflowParams(ctypes.Structure):
@@ -53,6 +54,8 @@ PROTOTYPES = {
     "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_bgr8": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i]),
     "hsflow_set_frames_gray8_blur": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_set_frames_bgr8_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i]),
+    "hsflow_set_frames_gray8_blur_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_push_frame_u8": (_i, [_vp, _i, _vp, _sz]),
     "hsflow_solve": (_i, [_vp, _pp]),
     "hsflow_solve_async": (_i, [_vp, _pp]),
@@ -77,6 +80,7 @@ PROTOTYPES = {
     "hsflow_pipeline_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i]),
     "hsflow_pipeline_destroy": (_i, [_vp]),
     "hsflow_pipeline_submit": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
+    "hsflow_pipeline_submit_ex": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
     "hsflow_pipeline_wait": (_i, [_vp, ctypes.c_uint64]),
     "hsflow_pipeline_info": (_i, [_vp, ctypes.c_uint64, ctypes.POINTER(HsflowInfo)]),
     "hsflow_pipeline_drain": (_i, [_vp]),

@@ -247,29 +247,35 @@ int hsflow_push_frame_u8(hsflow_ctx *c, int pair, const uint8_t *next, size_t ns
     return HSFLOW_OK;
 }
 
-// Upload one host frame (colour or gray) into scratch, convert / blur on the device into dst.
-static int preprocess_frame(hsflow_ctx *c, uint8_t *dst, const uint8_t *host, size_t stride, bool colour, bool blur)
+// Upload one host frame (colour or gray) into scratch, convert / blur on the device into dst.  `slot`
+// (0 / 1) picks one of two scratch areas, so that the two frames of a pair can be in flight together;
+// sync = false only enqueues (host buffer must stay valid until the stream has passed the copy).
+static int preprocess_frame(hsflow_ctx *c, uint8_t *dst, const uint8_t *host, size_t stride, bool colour, bool blur, int slot = 0,
+                            bool sync = true)
 {
     const size_t bgr_bytes = (size_t)c->W * 3 * c->H, gray_bytes = (size_t)c->plane;
-    const size_t need = bgr_bytes + 2 * gray_bytes;
+    const size_t one = bgr_bytes + 2 * gray_bytes, need = 2 * one;
     if (c->scratch_bytes < need) {
+        HS_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still use the old area
         hipFree(c->dScratch);
         c->dScratch = nullptr; c->scratch_bytes = 0;
         HS_HIP(c, hipMalloc(&c->dScratch, need));
         c->scratch_bytes = need;
     }
-    uint8_t *dBgr = (uint8_t *)c->dScratch, *dGray = dBgr + bgr_bytes;
+    uint8_t *dBgr = (uint8_t *)c->dScratch + (size_t)slot * one, *dGray = dBgr + bgr_bytes;
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4), block(64, 4);
-    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if (sync) HS_HIP(c, hipStreamSynchronize(c->stream));
     if (colour) {
-        HS_HIP(c, hipMemcpy2D(dBgr, (size_t)c->W * 3, host, stride, (size_t)c->W * 3, c->H, hipMemcpyHostToDevice));
+        if (sync) HS_HIP(c, hipMemcpy2D(dBgr, (size_t)c->W * 3, host, stride, (size_t)c->W * 3, c->H, hipMemcpyHostToDevice));
+        else HS_HIP(c, copy_rows_async(c, dBgr, (size_t)c->W * 3, host, stride, (size_t)c->W * 3, c->H, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(hsk::k_bgr2gray, grid, block, 0, c->stream, dBgr, (long long)c->W * 3, blur ? dGray : dst, c->W, c->H, c->P);
     } else {
-        HS_HIP(c, hipMemcpy2D(blur ? dGray : dst, c->P, host, stride, c->W, c->H, hipMemcpyHostToDevice));
+        if (sync) HS_HIP(c, hipMemcpy2D(blur ? dGray : dst, c->P, host, stride, c->W, c->H, hipMemcpyHostToDevice));
+        else HS_HIP(c, copy_rows_async(c, blur ? dGray : dst, c->P, host, stride, c->W, c->H, hipMemcpyHostToDevice));
     }
     if (blur) hipLaunchKernelGGL(hsk::k_box_blur3, grid, block, 0, c->stream, dGray, dst, c->W, c->H, c->P);
     HS_HIP(c, hipGetLastError());
-    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if (sync) HS_HIP(c, hipStreamSynchronize(c->stream));
     return HSFLOW_OK;
 }
 
@@ -296,6 +302,36 @@ int hsflow_set_frames_gray8_blur(hsflow_ctx *c, int pair, const uint8_t *prev, s
     if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
     if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, false, true))) return st;
     if ((st = preprocess_frame(c, c->dB + pair * c->plane, curr, cs, false, true))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+// Asynchronous forms: everything is only enqueued on ctx's stream (uploads into two scratch areas, then
+// the conversion / blur kernels); the host buffers belong to the context until hsflow_synchronize.
+int hsflow_set_frames_bgr8_async(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs, int blur3x3)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W * 3 || cs < (size_t)c->W * 3) return fail(c, HSFLOW_E_SIZE, "colour frame stride smaller than 3*width");
+    if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, true, blur3x3 != 0, 0, false))) return st;
+    if ((st = preprocess_frame(c, c->dB + pair * c->plane, curr, cs, true, blur3x3 != 0, 1, false))) return st;
+    c->frames_set = true;
+    c->coef_valid = false;
+    return HSFLOW_OK;
+}
+
+int hsflow_set_frames_gray8_blur_async(hsflow_ctx *c, int pair, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs)
+{
+    int st = check_ctx(c, pair);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
+    if (!prev || !curr) return fail(c, HSFLOW_E_ARG, "null frame pointer");
+    if (ps < (size_t)c->W || cs < (size_t)c->W) return fail(c, HSFLOW_E_SIZE, "frame stride smaller than width");
+    if ((st = preprocess_frame(c, c->dA + pair * c->plane, prev, ps, false, true, 0, false))) return st;
+    if ((st = preprocess_frame(c, c->dB + pair * c->plane, curr, cs, false, true, 1, false))) return st;
     c->frames_set = true;
     c->coef_valid = false;
     return HSFLOW_OK;

@@ -95,15 +95,27 @@ int hsflow_pipeline_destroy(hsflow_pipeline *pl)
 int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs,
                            float *u, size_t us, float *v, size_t vs, const hsflow_params *params, uint64_t *ticket)
 {
+    return hsflow_pipeline_submit_ex(pl, HSFLOW_FRAMES_GRAY8, prev, ps, curr, cs, u, us, v, vs, params, ticket);
+}
+
+int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *prev, size_t ps, const uint8_t *curr, size_t cs,
+                              float *u, size_t us, float *v, size_t vs, const hsflow_params *params, uint64_t *ticket)
+{
     if (!pl) return HSFLOW_E_ARG;
+    if (format < HSFLOW_FRAMES_GRAY8 || format > HSFLOW_FRAMES_BGR8_BLUR) return pfail(pl, HSFLOW_E_ARG, "unknown frame format");
     if (!params) return pfail(pl, HSFLOW_E_ARG, "params is null");
     if (!u || !v) return pfail(pl, HSFLOW_E_ARG, "null flow pointer");
     hsflow_pipeline::Slot &s = pl->slots[pl->next % pl->slots.size()];
     int st = finish_slot(pl, s); // the job that used this slot `depth` submissions ago
     if (st) return st;
-    if ((st = hsflow_set_frames_u8_async(s.ctx, 0, prev, ps, curr, cs))) {
+    switch (format) { // the reference CPU route's pre-processing (gray, 3x3 blur) can ride along on the device
+    case HSFLOW_FRAMES_GRAY8: st = hsflow_set_frames_u8_async(s.ctx, 0, prev, ps, curr, cs); break;
+    case HSFLOW_FRAMES_GRAY8_BLUR: st = hsflow_set_frames_gray8_blur_async(s.ctx, 0, prev, ps, curr, cs); break;
+    default: st = hsflow_set_frames_bgr8_async(s.ctx, 0, prev, ps, curr, cs, format == HSFLOW_FRAMES_BGR8_BLUR); break;
+    }
+    if (st) {
         hsflow_synchronize(s.ctx); // one of the two uploads may have been queued already
-        return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_async");
+        return ctx_fail(pl, s.ctx, st, "upload of the frames");
     }
     if ((st = hsflow_solve_async(s.ctx, params))) {
         hsflow_synchronize(s.ctx); // the uploads were queued: do not leave them reading caller memory

@@ -47,10 +47,17 @@ class PairPipeline(object):
         if st:
             raise HsflowError(st, (self._lib.hsflow_pipeline_last_error(self._h) or b"").decode())
 
-    def submit(self, prev, curr, u_out, v_out, params=None, **kw):
-        """Enqueues upload -> solve -> download of one pair; returns its ticket.  The four arrays
-        belong to the pipeline until `wait(ticket)` (or `drain()`) returned."""
-        for a, dt in ((prev, np.uint8), (curr, np.uint8), (u_out, np.float32), (v_out, np.float32)):
+    def submit(self, prev, curr, u_out, v_out, params=None, frames="gray", **kw):
+        """Enqueues upload -> [pre-processing] -> solve -> download of one pair; returns its ticket.  The four
+        arrays belong to the pipeline until `wait(ticket)` (or `drain()`) returned.
+        frames: "gray" (u8, as is), "gray_blur" (3x3 box blur on the device), "bgr" / "bgr_blur" ((H, W, 3) u8)."""
+        fmt = {"gray": _lib.FRAMES_GRAY8, "gray_blur": _lib.FRAMES_GRAY8_BLUR, "bgr": _lib.FRAMES_BGR8, "bgr_blur": _lib.FRAMES_BGR8_BLUR}[frames]
+        colour = fmt >= _lib.FRAMES_BGR8
+        for a in (prev, curr):
+            want = (self.height, self.width, 3) if colour else (self.height, self.width)
+            if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.shape != want or a.strides[-1] != 1 or (colour and a.strides[1] != 3):
+                raise ValueError("frames must be u8 arrays of shape %r with packed pixels" % (want,))
+        for a, dt in ((u_out, np.float32), (v_out, np.float32)):
             if not isinstance(a, np.ndarray) or a.dtype != dt or a.shape != (self.height, self.width) or a.strides[1] != a.itemsize:
                 raise ValueError("pipeline buffers must be (height, width) arrays: u8 frames, fp32 flow, unit column stride")
         if not (u_out.flags.writeable and v_out.flags.writeable):
@@ -59,8 +66,8 @@ class PairPipeline(object):
             kw.setdefault("term_type", TERM_ITER)
             params = make_params(**kw)
         t = ctypes.c_uint64()
-        self._check(self._lib.hsflow_pipeline_submit(
-            self._h, ctypes.c_void_p(prev.ctypes.data), prev.strides[0], ctypes.c_void_p(curr.ctypes.data), curr.strides[0],
+        self._check(self._lib.hsflow_pipeline_submit_ex(
+            self._h, fmt, ctypes.c_void_p(prev.ctypes.data), prev.strides[0], ctypes.c_void_p(curr.ctypes.data), curr.strides[0],
             ctypes.c_void_p(u_out.ctypes.data), u_out.strides[0], ctypes.c_void_p(v_out.ctypes.data), v_out.strides[0],
             ctypes.byref(params), ctypes.byref(t)))
         self._held.pop(t.value - self.depth, None)  # that slot was waited for inside submit

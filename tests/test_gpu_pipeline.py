@@ -166,3 +166,52 @@ def test_pipeline_iter_eps_like_the_reference_call(hs, oracle, gpu_ok):
     uo, vo, n_o, _ = oracle.calc_optical_flow_hs(pairs[1][0], pairs[1][1], 0.3, it, eps6, 3, return_info=True)
     assert n_o == ref[1][1]
     assert np.sqrt(np.mean((outs[1][1].astype(np.float64) - uo) ** 2)) <= RMS_TOL
+
+
+def test_pipeline_runs_the_cpu_routes_preprocessing_on_the_device(hs, oracle, gpu_ok):
+    """Colour frames in, flow out: BGR->gray and the 3x3 blur of OpticalFlowOpenCV::runFromImg ride along in
+    each pair's queue.  Must equal the synchronous entry points and the oracle chain, for every format."""
+    W, H, it = 150, 90, 14
+    eps6 = float(np.float32(1e-6))
+    rng = np.random.default_rng(4)
+    pairs = [(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8), rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)) for _ in range(5)]
+    crit = dict(lam=0.2, max_iter=it, epsilon=eps6, term_type=hs.TERM_ITER | hs.TERM_EPS)
+    for frames in ("bgr_blur", "bgr", "gray_blur", "gray"):
+        colour = frames.startswith("bgr")
+        ref = []
+        with hs.HSFlow(W, H, own_stream=True) as ctx:
+            for A, B in pairs:
+                a, b = (A, B) if colour else (oracle.bgr2gray(A), oracle.bgr2gray(B))
+                if frames == "bgr_blur":
+                    ctx.set_frames_bgr(a, b, blur=True)
+                elif frames == "bgr":
+                    ctx.set_frames_bgr(a, b, blur=False)
+                elif frames == "gray_blur":
+                    ctx.set_frames_gray_blur(a, b)
+                else:
+                    ctx.set_frames(a, b)
+                ctx.solve(**crit)
+                ref.append(ctx.flow())
+        with hs.PairPipeline(W, H, depth=3) as pl:
+            outs = []
+            for A, B in pairs:
+                src = (A, B) if colour else (oracle.bgr2gray(A), oracle.bgr2gray(B))
+                shape = (H, W, 3) if colour else (H, W)
+                a, b = hs.pinned_empty(shape, np.uint8), hs.pinned_empty(shape, np.uint8)
+                a[...], b[...] = src
+                u, v = hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)
+                pl.submit(a, b, u, v, frames=frames, **crit)
+                outs.append((u, v))
+            pl.drain()
+        for k, ((u, v), (ur, vr)) in enumerate(zip(outs, ref)):
+            assert np.array_equal(u, ur) and np.array_equal(v, vr), (frames, k)
+    # the oracle chain for the full route
+    A, B = pairs[0]
+    ga, gb = oracle.box_blur3(oracle.bgr2gray(A)), oracle.box_blur3(oracle.bgr2gray(B))
+    uo, vo = oracle.calc_optical_flow_hs(ga, gb, 0.2, it, eps6, 3)
+    with hs.PairPipeline(W, H, depth=2) as pl:
+        u, v = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+        pl.wait(pl.submit(A, B, u, v, frames="bgr_blur", **crit))
+        assert np.sqrt(np.mean((u.astype(np.float64) - uo) ** 2)) <= RMS_TOL and np.sqrt(np.mean((v.astype(np.float64) - vo) ** 2)) <= RMS_TOL
+        with pytest.raises(ValueError):
+            pl.submit(A[:, :, 0], B, u, v, frames="bgr", **crit)
