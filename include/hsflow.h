@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define HSFLOW_VERSION_MAJOR 0
-#define HSFLOW_VERSION_MINOR 1
+#define HSFLOW_VERSION_MINOR 2
 
 /* status codes (0 = success, like SDK_SUCCESS) */
 #define HSFLOW_OK 0
