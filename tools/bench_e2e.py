@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--pairs", type=int, default=200)
     ap.add_argument("--depths", default="1,2,3,4")
+    ap.add_argument("--frames", default="gray", choices=["gray", "gray_blur", "bgr", "bgr_blur"],
+                    help="layout of the host frames (bgr*: 3 bytes / pixel, pre-processing on the device)")
     args = ap.parse_args()
 
     import torch
@@ -59,24 +61,25 @@ def main():
             mk = hs.pinned_empty if pinned else (lambda s, d: np.empty(s, d))
             bufs = []
             for i in range(max(nbuf, depth + 1)):
-                a, b = mk((H, W), np.uint8), mk((H, W), np.uint8)
-                a[...] = A
-                b[...] = B
+                fshape = (H, W, 3) if args.frames.startswith("bgr") else (H, W)
+                a, b = mk(fshape, np.uint8), mk(fshape, np.uint8)
+                a[...] = A[..., None] if len(fshape) == 3 else A
+                b[...] = B[..., None] if len(fshape) == 3 else B
                 bufs.append((a, b, mk((H, W), np.float32), mk((H, W), np.float32)))
             with hs.PairPipeline(W, H, depth=depth) as pl:
                 p = hs.make_params(lam=1.0, max_iter=args.iters, term_type=hs.TERM_ITER, use_graph=True)
                 for i in range(2 * len(bufs)):
-                    pl.submit(*bufs[i % len(bufs)], params=p)
+                    pl.submit(*bufs[i % len(bufs)], params=p, frames=args.frames)
                 pl.drain()
                 t0 = time.perf_counter()
                 for i in range(args.pairs):
-                    pl.submit(*bufs[i % len(bufs)], params=p)  # a buffer set is reused only after its slot was recycled
+                    pl.submit(*bufs[i % len(bufs)], params=p, frames=args.frames)  # a buffer set is reused only after its slot was recycled
                 pl.drain()
                 dt = time.perf_counter() - t0
-            emit({"e2e": "pipeline", "pinned": pinned, "depth": depth, "width": W, "height": H, "iters": args.iters,
+            emit({"e2e": "pipeline", "frames": args.frames, "pinned": pinned, "depth": depth, "width": W, "height": H, "iters": args.iters,
                   "pairs": args.pairs, "pairs_per_s": round(args.pairs / dt, 1), "ms_per_pair": round(dt / args.pairs * 1e3, 4),
                   "mpix_iter_per_s": round(W * H * args.iters * args.pairs / dt / 1e6, 0),
-                  "pcie_GB_per_s": round((2 * W * H + 8 * W * H) * args.pairs / dt / 1e9, 2)})
+                  "pcie_GB_per_s": round(((6 if args.frames.startswith("bgr") else 2) * W * H + 8 * W * H) * args.pairs / dt / 1e9, 2)})
     # resident reference point: same solve, no host traffic
     with hs.HSFlow(W, H, own_stream=True) as ctx:
         ctx.set_frames(A, B)
