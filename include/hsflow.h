@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define HSFLOW_VERSION_MAJOR 0
-#define HSFLOW_VERSION_MINOR 2
+#define HSFLOW_VERSION_MINOR 3 /* 0.3: hsflow_info.deriv_fused */
 
 /* status codes (0 = success, like SDK_SUCCESS) */
 #define HSFLOW_OK 0
@@ -117,6 +117,8 @@ typedef struct hsflow_info {
     float solve_ms;           /* profile=1: first event to last event of the solve        */
     int32_t eps_rerun;        /* ITER|EPS: 1 if the fast pass could not prove "no early stop"
                                  and the solve was repeated with Eps measured in every sweep */
+    int32_t deriv_fused;      /* 1 if the derivative pass ran inside the first Jacobi launch of the
+                                 last solve instead of as a kernel of its own                    */
 } hsflow_info;
 
 /* --- lifecycle ---------------------------------------------------------------------------- */

@@ -38,7 +38,8 @@ class HsflowInfo(ctypes.Structure):
                 ("groups_per_thread", ctypes.c_int32), ("tiles", ctypes.c_int32),
                 ("lds_bytes", ctypes.c_int32), ("jacobi_launches", ctypes.c_int32),
                 ("deriv_ms", ctypes.c_float), ("jacobi_ms", ctypes.c_float),
-                ("solve_ms", ctypes.c_float), ("eps_rerun", ctypes.c_int32)]
+                ("solve_ms", ctypes.c_float), ("eps_rerun", ctypes.c_int32),
+                ("deriv_fused", ctypes.c_int32)]
 
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t

@@ -89,8 +89,58 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     vQ = f2_fma(-c.beQ, qQ, vbQ);
 }
 
-template <int R, int NTMAX, int EPS>
-__global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
+// The packed derivative words of a lane's R rows straight from the two frames (DERIV launches: the first
+// launch of a solve then needs no separate derivative pass).  Same arithmetic as k_deriv_cv, on the EVEN
+// REFLECTION of frame A -- which is the replicate border at the image edge (A(-1) = A(0)) and, further out,
+// yields the derivative of the mirrored pixel with the sign of the component across the mirror flipped; the
+// flip is undone here because the halo wants the mirrored pixel's coefficients unchanged.  The column
+// neighbours x0-1 and x0+4 come from the adjacent lanes (the region is contiguous in the reflected image);
+// lanes 0 and 63 have none, so the region's outermost columns get a wrong Ix -- they are invalid after the
+// first sweep anyway (HX >= T >= 1).  Host-side conditions (launch_j): W % 4 == 0 and the image at least as
+// large as the region, so a group is wholly inside or wholly mirrored and one bounce suffices.
+// Register row r of the lane is image row y0 + dir * r (dir = -1: the folded kernel's lower half, whose
+// registers run bottom-up).
+template <int R>
+__device__ __forceinline__ void strip_derive(const uint8_t *__restrict__ fA, const uint8_t *__restrict__ fB,
+                                             const StripGeom &g, long long base, int x0, int y0, int dir, bool xin,
+                                             uint4 (&lc)[R])
+{
+    int xg = x0;
+    if (!xin) {
+        xg = x0 < 0 ? -x0 - 4 : 2 * g.W - x0 - 4;
+        if (xg < 0 || xg + 4 > g.W) xg = 0; // excluded by the host; keeps the load inside the row regardless
+    }
+    int a[R + 2][6]; // columns x0-1 .. x0+4 of the reflected rows y0 - dir, y0, ..., y0 + dir * R
+#pragma unroll
+    for (int j = 0; j < R + 2; j++) {
+        uint32_t wd = *(const uint32_t *)(fA + base + (long long)mirror_index(y0 + dir * (j - 1), g.H) * g.P + xg);
+        if (!xin) wd = __builtin_bswap32(wd);
+        a[j][0] = (int)((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd, 0x138, 0xF, 0xF, true) >> 24);
+        a[j][5] = (int)((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd, 0x130, 0xF, 0xF, true) & 0xFFu);
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[j][k + 1] = (int)((wd >> (8 * k)) & 0xFFu);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int y = y0 + dir * r;
+        uint32_t wb = *(const uint32_t *)(fB + base + (long long)mirror_index(y, g.H) * g.P + xg);
+        if (!xin) wb = __builtin_bswap32(wb);
+        const bool yflip = (y < 0 || y >= g.H) != (dir < 0); // a[r + 2] is the row BELOW only when dir > 0
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int ix8 = (a[r][k + 2] + 2 * a[r + 1][k + 2] + a[r + 2][k + 2]) - (a[r][k] + 2 * a[r + 1][k] + a[r + 2][k]);
+            int iy8 = (a[r + 2][k] + 2 * a[r + 2][k + 1] + a[r + 2][k + 2]) - (a[r][k] + 2 * a[r][k + 1] + a[r][k + 2]);
+            if (!xin) ix8 = -ix8;
+            if (yflip) iy8 = -iy8;
+            o[k] = pack_deriv(ix8, iy8, (int)((wb >> (8 * k)) & 0xFFu) - a[r + 1][k + 1]);
+        }
+        lc[r] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int R, int NTMAX, int EPS, bool DERIV>
+__device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in,
                                                         float *__restrict__ u_out,
@@ -98,7 +148,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         const float ilambda,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
-                                                        const float eps_thr)
+                                                        const float eps_thr, const uint8_t *__restrict__ fA,
+                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
 {
     // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
     // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
@@ -157,7 +208,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 lu[r] = *(const float4 *)(u_in + off);
                 lv[r] = *(const float4 *)(v_in + off);
             }
-            lc[r] = *(const uint4 *)(coef + off);
+            if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
         }
     } else {
 #pragma unroll
@@ -180,7 +231,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                 a = *(const float4 *)(u_in + row + xg);
                 b = *(const float4 *)(v_in + row + xg);
             }
-            uint4 c = *(const uint4 *)(coef + row + xg);
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            if (!DERIV) c = *(const uint4 *)(coef + row + xg);
             if (rev) {
                 a = make_float4(a.w, a.z, a.y, a.x);
                 b = make_float4(b.w, b.z, b.y, b.x);
@@ -188,18 +240,21 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
             }
             if (slow) { // volatile keeps this a separate, rarely taken path
                 const volatile float *uv = u_in + row, *vv = v_in + row;
-                const volatile uint32_t *cv = coef + row;
                 const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
                           xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
                 if (!g.zero_in) {
                     a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
                     b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
                 }
-                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                if (!DERIV) {
+                    const volatile uint32_t *cv = coef + row;
+                    c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                }
             }
             lu[r] = a; lv[r] = b; lc[r] = c;
         }
     }
+    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, y0, 1, xin, lc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const float4 lu_ = lu[r], lv_ = lv[r];
@@ -225,6 +280,11 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     }
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
+    if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((rowcore >> r) & 1u) *(uint4 *)(coef_w + base + (long long)(y0 + r) * g.P + x0) = lc[r];
+    }
 
     // One row update.  up*/dn* are OLD neighbour rows; the new row replaces uP[r].. in place.
     // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
@@ -416,6 +476,40 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
     }
 }
 
+template <int R, int NTMAX, int EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
+                                                        const float *__restrict__ u_in,
+                                                        const float *__restrict__ v_in,
+                                                        float *__restrict__ u_out,
+                                                        float *__restrict__ v_out, const StripGeom g,
+                                                        const float ilambda,
+                                                        unsigned *__restrict__ eps_out, const int eps_stride,
+                                                        unsigned long long *__restrict__ stamps,
+                                                        const float eps_thr)
+{
+    strip_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+                                     nullptr, nullptr, nullptr);
+}
+
+// First launch of a solve with the derivative pass folded in: reads the two frames instead of the packed
+// derivative plane and writes that plane for the launches that follow (and for hsflow_get_derivatives).
+template <int R, int NTMAX, int EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__restrict__ fA,
+                                                              const uint8_t *__restrict__ fB,
+                                                              uint32_t *__restrict__ coef_w,
+                                                              const float *__restrict__ u_in,
+                                                              const float *__restrict__ v_in,
+                                                              float *__restrict__ u_out,
+                                                              float *__restrict__ v_out, const StripGeom g,
+                                                              const float ilambda,
+                                                              unsigned *__restrict__ eps_out, const int eps_stride,
+                                                              unsigned long long *__restrict__ stamps,
+                                                              const float eps_thr)
+{
+    strip_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+                                    fA, fB, coef_w);
+}
+
 // ------------------------------------------------------------------------------------------
 // a2, form 4: "folded" strips.  Same register-resident scheme as k_jacobi_strip, but one wavefront
 // holds TWO vertically adjacent strips of 128 columns: lanes 0-31 the upper one (rows top->bottom
@@ -438,8 +532,8 @@ __device__ __forceinline__ float lane_xor32(float x, bool lower)
     return __uint_as_float(lower ? r[0] : r[1]);
 }
 
-template <int R, int NTMAX, int EPS> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
-__global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
+template <int R, int NTMAX, int EPS, bool DERIV> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
+__device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                                                        const float *__restrict__ u_in,
                                                        const float *__restrict__ v_in,
                                                        float *__restrict__ u_out,
@@ -447,7 +541,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        const float ilambda,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps,
-                                                       const float eps_thr)
+                                                       const float eps_thr, const uint8_t *__restrict__ fA,
+                                                       const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
 {
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -489,7 +584,8 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
             a = *(const float4 *)(u_in + row + xg);
             b = *(const float4 *)(v_in + row + xg);
         }
-        uint4 c = *(const uint4 *)(coef + row + xg);
+        uint4 c = make_uint4(0u, 0u, 0u, 0u);
+        if (!DERIV) c = *(const uint4 *)(coef + row + xg);
         if (side) {
             if (rev) {
                 a = make_float4(a.w, a.z, a.y, a.x);
@@ -498,18 +594,22 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
             }
             if (slow) { // volatile keeps this a separate, rarely taken path
                 const volatile float *uv = u_in + row, *vv = v_in + row;
-                const volatile uint32_t *cv = coef + row;
                 const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
                           xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
                 if (!g.zero_in) {
                     a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
                     b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
                 }
-                c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                if (!DERIV) {
+                    const volatile uint32_t *cv = coef + row;
+                    c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                }
             }
         }
         lu[r] = a; lv[r] = b; lc[r] = c;
     }
+    // (the wave shifts in strip_derive cross the lane 31/32 seam like those of the sweep: region-edge columns)
+    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         uP[r] = f2{lu[r].x, lu[r].y}; uQ[r] = f2{lu[r].z, lu[r].w};
@@ -536,6 +636,12 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
     }
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * hl >= g.HX) && (4 * hl < g.HX + g.CW);
     const int pr = g.W - 1 - x0;
+    if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((rowcore >> r) & 1u)
+                *(uint4 *)(coef_w + base + (long long)(yb + (lower ? 2 * R - 1 - r : r)) * g.P + x0) = lc[r];
+    }
 
 #define HF_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
     do {                                                                                           \
@@ -658,6 +764,39 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
         o[7] = (unsigned long long)tile;
     }
+}
+
+template <int R, int NTMAX, int EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
+                                                       const float *__restrict__ u_in,
+                                                       const float *__restrict__ v_in,
+                                                       float *__restrict__ u_out,
+                                                       float *__restrict__ v_out, const StripGeom g,
+                                                       const float ilambda,
+                                                       unsigned *__restrict__ eps_out, const int eps_stride,
+                                                       unsigned long long *__restrict__ stamps,
+                                                       const float eps_thr)
+{
+    fold_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+                                    nullptr, nullptr, nullptr);
+}
+
+// The folded kernel as the first launch of a solve, derivative pass included (see k_jacobi_strip_deriv).
+template <int R, int NTMAX, int EPS>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_fold_deriv(const uint8_t *__restrict__ fA,
+                                                             const uint8_t *__restrict__ fB,
+                                                             uint32_t *__restrict__ coef_w,
+                                                             const float *__restrict__ u_in,
+                                                             const float *__restrict__ v_in,
+                                                             float *__restrict__ u_out,
+                                                             float *__restrict__ v_out, const StripGeom g,
+                                                             const float ilambda,
+                                                             unsigned *__restrict__ eps_out, const int eps_stride,
+                                                             unsigned long long *__restrict__ stamps,
+                                                             const float eps_thr)
+{
+    fold_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+                                   fA, fB, coef_w);
 }
 
 } // namespace hsk

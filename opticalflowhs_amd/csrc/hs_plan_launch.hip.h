@@ -258,6 +258,57 @@ hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *
     return hipErrorInvalidConfiguration;
 }
 
+// The strip / folded kernel with the derivative pass in its load phase (first launch of a solve).
+template <int R, int NTMAX, int EPS, bool FOLD>
+hipError_t launch_strip_deriv_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                                float *uo, float *vo, float coeff, bool configure_only)
+{
+    auto kern = [] {
+        if constexpr (FOLD) return hsk::k_jacobi_fold_deriv<R, NTMAX, EPS>;
+        else return hsk::k_jacobi_strip_deriv<R, NTMAX, EPS>;
+    }();
+    static bool configured[64] = {};
+    if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi,
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
+    return hipGetLastError();
+}
+
+template <int EPS, bool FOLD>
+hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                                float *uo, float *vo, float coeff, bool cfg)
+{
+    switch (p.R) { // the same thread limits as launch_strip_e
+    case 1: return launch_strip_deriv_t<1, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 2: return launch_strip_deriv_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 3: return launch_strip_deriv_t<3, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 4: return launch_strip_deriv_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 5:
+        if (!FOLD && EPS && p.g.NW <= 12) return launch_strip_deriv_t<5, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+        return launch_strip_deriv_t<5, FOLD ? 768 : 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    case 6: return launch_strip_deriv_t<6, FOLD ? 512 : 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+// Can the first launch of a solve compute the derivatives itself (k_jacobi_strip_deriv / k_jacobi_fold_deriv)?
+// The kernels' reflection argument wants whole 4-pixel groups inside or outside the image and a single
+// bounce: an image at least as large as one workgroup's region (256 or 128 columns x all its rows).
+bool strip_deriv_fusable(const hsflow_ctx *c, const JPlan &pl)
+{
+    static const bool off = getenv("HSFLOW_NO_DERIV_FUSION") != nullptr;
+    if (off || (pl.kind != HSFLOW_KERNEL_STRIP && pl.kind != HSFLOW_KERNEL_FOLD)) return false;
+    if (pl.s.R < 1 || pl.s.R > 6) return false; // 7 and 8 rows per lane: not instantiated
+    const int region_w = pl.s.fold ? 128 : 256, region_h = pl.s.g.NW * pl.s.R * (pl.s.fold ? 2 : 1);
+    return (c->W & 3) == 0 && c->W >= region_w && c->H >= region_h;
+}
+
 bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)
 {
     out.kind = kind;
@@ -268,12 +319,19 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
 }
 
 // eps: 0 none, 1 Eps of every sweep, 2 witness (strip kernel only: one lower bound per launch)
+// deriv: this launch also does the derivative pass (only where strip_deriv_fusable() said so)
 hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *ui, const float *vi,
-                    float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0)
+                    float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0, bool deriv = false)
 {
     if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         StripPlan sp = pl.s;
         sp.g.zero_in = zero_in;
+        if (deriv && sp.fold) return eps == 2 ? launch_strip_deriv_e<2, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                     : eps  ? launch_strip_deriv_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                            : launch_strip_deriv_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        if (deriv) return eps == 2 ? launch_strip_deriv_e<2, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                          : eps  ? launch_strip_deriv_e<1, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                 : launch_strip_deriv_e<0, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
         if (sp.fold) return eps == 2 ? launch_strip_e<2, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
                             : eps  ? launch_strip_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
                                    : launch_strip_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);

@@ -77,7 +77,11 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
     // planes and reading them back, the first launch is told that its input is zero.
     int zero_in = zero_flow ? 1 : 0;
     if (zero_flow) c->cur = 0;
-    if (do_deriv) {
+    // the derivative pass rides in the first Jacobi launch where the kernel can do it (not when profiling:
+    // deriv_ms / jacobi_ms then keep their meaning)
+    bool fuse = do_deriv && !p.profile && kernel != HSFLOW_KERNEL_SIMPLE &&
+                strip_deriv_fusable(c, iters >= T ? *plan : *tail_plan);
+    if (do_deriv && !fuse) {
         prof.begin(0);
         HS_HIP(c, launch_deriv(c));
         prof.end();
@@ -93,8 +97,9 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
         } else {
             const JPlan *pl = (left >= T) ? plan : tail_plan;
             prof.begin(1);
-            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in));
+            HS_HIP(c, launch_j(c, *pl, false, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_in, fuse));
             prof.end();
+            fuse = false;
             left -= pl->T;
         }
         c->cur = b;
@@ -102,7 +107,6 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
         launches++;
     }
     c->info.jacobi_launches = launches;
-    (void)p;
     return HSFLOW_OK;
 }
 

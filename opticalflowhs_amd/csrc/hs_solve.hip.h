@@ -184,6 +184,7 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
         return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
     const bool zero = !p.use_previous;
     const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
+    c->info.deriv_fused = do_deriv && !p.profile && multi && strip_deriv_fusable(c, iters >= T ? plan : tail); // enqueue_fixed's rule
     if (p.use_graph && !p.profile) {
         GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                      c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff};
@@ -191,6 +192,9 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
             if (multi) {
                 HS_HIP(c, launch_j(c, plan, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (rem) HS_HIP(c, launch_j(c, tail, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                const JPlan &first = iters >= T ? plan : tail;
+                if (do_deriv && strip_deriv_fusable(c, first))
+                    HS_HIP(c, launch_j(c, first, false, nullptr, nullptr, nullptr, nullptr, coeff, true, 0, true));
             }
             return HSFLOW_OK;
         };
@@ -270,13 +274,18 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         const int slots = (n_launch - 1) + last_chunk;
         if ((st = eps_reserve(c, slots, stride))) return st;
         const int cur0 = c->cur;
+        // the first launch also does the derivative pass where the kernel can (hs_plan_launch.hip.h)
+        const JPlan &firstp = (n_launch == 1 && last_chunk != T) ? tailp : plan;
+        const bool fuse_deriv = do_deriv && !p.profile && strip_deriv_fusable(c, firstp);
+        c->info.deriv_fused = fuse_deriv;
         // the whole pass as one enqueue sequence (nothing allocated, nothing synchronised: capturable)
         auto enqueue = [&]() -> int {
             int e0 = save_start();
             if (e0) return e0;
             c->epsStride = stride;
             if ((e0 = eps_clear(c, slots, stride))) return e0;
-            if (do_deriv) {
+            bool fuse = fuse_deriv;
+            if (do_deriv && !fuse) {
                 prof.begin(0);
                 HS_HIP(c, launch_deriv(c));
                 prof.end();
@@ -289,11 +298,12 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 const int a = c->cur, b = a ^ 1;
                 c->epsPtr = c->dEpsTiles + (size_t)L * stride;
                 prof.begin(1);
-                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w);
+                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w, fuse);
                 prof.end();
                 HS_HIP(c, e);
                 c->cur = b;
                 zero_w = 0;
+                fuse = false;
                 launches++;
             }
             return eps_collect_enqueue(c, slots);
@@ -305,6 +315,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 HS_HIP(c, launch_j(c, plan, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (has_tail) HS_HIP(c, launch_j(c, tailp, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (fuse_deriv) HS_HIP(c, launch_j(c, firstp, n_launch == 1 ? 1 : 2, nullptr, nullptr, nullptr, nullptr, coeff, true, 0, true));
                 return HSFLOW_OK;
             };
             auto enqueue_n = [&](int *n) -> int {
@@ -555,6 +566,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) return solve_classic(c, p, async);
     if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
     c->info.eps_rerun = 0;
+    c->info.deriv_fused = 0;
     SolveSetup S;
     if ((st = prepare_solve(c, p, async, S))) return st;
     c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;

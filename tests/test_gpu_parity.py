@@ -143,6 +143,58 @@ def test_kernel_variants_are_bit_identical(hs, gpu_ok):
             assert np.array_equal(u, ref[0]) and np.array_equal(v, ref[1]), kw
 
 
+def test_derivative_pass_fused_into_first_launch(hs, oracle, gpu_ok):
+    """The strip kernel's first launch computing the derivatives itself (k_jacobi_strip_deriv) against the
+    separate derivative kernel (profile=True never fuses): the same flow bits, and the derivative plane it
+    leaves behind equals the oracle's -- over image borders in every tile position, mirrored halos, all
+    three Eps variants, warm starts and shapes where the fusion must be declined."""
+    cases = [(1920, 1080), (256, 96), (260, 131), (512, 200), (1024, 333), (300, 257), (258, 140), (264, 80), (2048, 97),
+             (424, 240), (600, 480), (128, 64), (132, 33), (124, 300)]
+    for n, (W, H) in enumerate(cases):
+        A, B = synth.random_pair(W, H, seed=70 + n)
+        Ix, Iy, It = oracle.derivatives(A, B)
+        with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+            ctx.set_frames(A, B)
+            for it, R, graph, kern in ((1, 5, False, hs.KERNEL_STRIP), (7, 4, True, hs.KERNEL_STRIP), (25, 5, True, hs.KERNEL_STRIP),
+                                       (43, 6, False, hs.KERNEL_STRIP), (20, 0, True, hs.KERNEL_STRIP), (9, 2, True, hs.KERNEL_STRIP),
+                                       (5, 7, False, hs.KERNEL_STRIP), (10, 0, True, hs.KERNEL_AUTO),
+                                       (1, 1, False, hs.KERNEL_FOLD), (13, 2, True, hs.KERNEL_FOLD), (8, 3, False, hs.KERNEL_FOLD),
+                                       (30, 4, True, hs.KERNEL_FOLD), (17, 5, False, hs.KERNEL_FOLD), (6, 6, True, hs.KERNEL_FOLD),
+                                       (50, 0, True, hs.KERNEL_FOLD)):
+                kw = dict(lam=0.5, max_iter=it, kernel=kern, strip_rows=R)
+                for tt in (ITER, ITER | EPS):
+                    for prev in (False, True):
+                        if prev:  # the warm start: the flow a short solve leaves on the device
+                            ctx.solve(lam=2.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_SIMPLE)
+                        i1 = ctx.solve(term_type=tt, epsilon=1e-6, use_previous=prev, use_graph=graph, **kw)
+                        u1, v1 = ctx.flow()
+                        dx, dy, dt = ctx.derivatives()
+                        fold = i1["kernel"] == hs.KERNEL_FOLD
+                        rows = (i1["threads"] // 64) * i1["groups_per_thread"] * (2 if fold else 1)
+                        fusable = i1["kernel"] in (hs.KERNEL_STRIP, hs.KERNEL_FOLD) and W % 4 == 0 and \
+                            W >= (128 if fold else 256) and H >= rows and i1["groups_per_thread"] <= 6
+                        assert i1["deriv_fused"] == (1 if fusable else 0), (W, H, it, R, tt, prev, i1)
+                        assert np.array_equal(dx, Ix) and np.array_equal(dy, Iy) and np.array_equal(dt, It), (W, H, it, R, tt, prev)
+                        if prev:
+                            ctx.solve(lam=2.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_SIMPLE)
+                        i2 = ctx.solve(term_type=tt, epsilon=1e-6, use_previous=prev, profile=True, **kw)
+                        u2, v2 = ctx.flow()
+                        assert i2["deriv_fused"] == 0
+                        assert i1["iterations_done"] == i2["iterations_done"] == it
+                        assert np.array_equal(u1, u2) and np.array_equal(v1, v2), (W, H, it, R, tt, prev)
+            # a fresh pair on the same context: the plane must be recomputed, not reused
+            A2, B2 = synth.random_pair(W, H, seed=170 + n)
+            ctx.set_frames(A2, B2)
+            ctx.solve(lam=0.5, max_iter=9, term_type=ITER, kernel=hs.KERNEL_AUTO, use_graph=True)
+            u1, v1 = ctx.flow()
+            dx, dy, dt = ctx.derivatives()
+            J = oracle.derivatives(A2, B2)
+            assert np.array_equal(dx, J[0]) and np.array_equal(dy, J[1]) and np.array_equal(dt, J[2])
+            ctx.solve(lam=0.5, max_iter=9, term_type=ITER, kernel=hs.KERNEL_STRIP, profile=True)
+            u2, v2 = ctx.flow()
+            assert np.array_equal(u1, u2) and np.array_equal(v1, v2)
+
+
 def test_eps_termination_matches_oracle(hs, gpu_ok):
     d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
     for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5),

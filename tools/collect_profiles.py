@@ -38,8 +38,8 @@ def main():
         shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
     bench = json.load(open(os.path.join(src, "bench_trace.json")))
     shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(ROOT, "profiles", "%s_bench_under_rocprof.json" % tag))
-    kern = bench["roofline"]["kernel"]
-    out = {"tag": tag, "kernel": kern, "width": bench["config"]["width"], "height": bench["config"]["height"],
+    kern = bench["roofline"]["kernel"] + "<"  # "k_jacobi_strip<": not the first-launch variant k_jacobi_strip_deriv<
+    out = {"tag": tag, "kernel": kern[:-1], "width": bench["config"]["width"], "height": bench["config"]["height"],
            "fuse_steps": bench["config"]["fuse_steps"], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
     fetch = find(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"))
     write = find(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"))
