@@ -23,7 +23,7 @@ def _json_line(out):
 
 
 def test_bench_single_gpu_line(gpu_ok):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-iters", "5"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-iters", "5", "--cpu-seconds", "1"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
