@@ -63,13 +63,12 @@ struct hsflow_ctx {
     unsigned *dEps = nullptr;   // kMaxFuse words: Eps sink of launches that do not collect it
     unsigned *epsPtr = nullptr; // where the running launch records Eps: [sweep][epsStride] words
     float epsThr = 0.f;         // witness launches: smallest float >= epsilon
-    unsigned *hEps = nullptr;   // page-locked read-back buffer for the per-sweep Eps words
+    unsigned *hEps = nullptr;   // page-locked, device-visible: k_eps_reduce writes the per-sweep Eps words here
+    unsigned *hEpsDev = nullptr; // the device's address of hEps
     size_t hEpsCap = 0;
     int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
     unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
     size_t epsTilesCap = 0;
-    unsigned *dEpsAll = nullptr; // one word per sweep of a whole ITER|EPS solve (speculative run)
-    int epsAllCap = 0;
     float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;

@@ -443,17 +443,24 @@ namespace hsk {
 
 // Eps of every sweep = maximum over that sweep's row of per-workgroup values (bit patterns of
 // non-negative floats order like unsigned integers).  One workgroup per sweep.
+// Row r holds cnt_first valid words for r < n_first, else cnt_last (launches of different plans have
+// different workgroup counts; words beyond are never read, so nothing needs clearing).  `out` is
+// page-locked host memory seen through its device address: the words are on the host when the stream drains.
 __global__ __launch_bounds__(256) void k_eps_reduce(const unsigned *__restrict__ tiles, int stride,
-                                                    unsigned *__restrict__ out)
+                                                    unsigned *__restrict__ out, int n_first, int cnt_first, int cnt_last)
 {
     __shared__ unsigned part[4];
     const unsigned *row = tiles + (size_t)blockIdx.x * stride;
+    const int n = (int)blockIdx.x < n_first ? cnt_first : cnt_last;
     unsigned m = 0;
-    for (int i = threadIdx.x; i < stride; i += 256) m = max(m, row[i]);
+    for (int i = threadIdx.x; i < n; i += 256) m = max(m, row[i]);
     float f = wave_max(__uint_as_float(m));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __float_as_uint(f);
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+        __threadfence_system();
+    }
 }
 
 } // namespace hsk

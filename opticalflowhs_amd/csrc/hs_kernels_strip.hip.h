@@ -1,6 +1,17 @@
 // hs_kernels_strip.hip.h -- the register-resident multi-sweep Jacobi kernels (k_jacobi_strip, the default, and
 // its folded form k_jacobi_fold).  Included by hs_kernels.hip.h, which holds the shared arithmetic.
 #pragma once
+#include <type_traits>
+
+// Last sweep of a launch as a second copy of the sweep code after the loop (the loop then publishes and
+// meets the barrier unconditionally).  Folded kernel: far fewer spills (R = 4: 33 -> 7, R = 5: 33 -> 1) and
+// 15 VGPRs less at R = 3; strip kernel: slightly worse (R = 5 / 16 wavefronts: 2 -> 11 spills), so not there.
+#ifndef HS_PEEL_LAST_STRIP
+#define HS_PEEL_LAST_STRIP 0
+#endif
+#ifndef HS_PEEL_LAST_FOLD
+#define HS_PEEL_LAST_FOLD 1
+#endif
 
 namespace hsk {
 
@@ -160,6 +171,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // per-sweep answers in an SGPR.  Each |change| is a lower bound of that sweep's Eps, so a
     // wavefront that answered yes in EVERY sweep proves Eps_k >= eps_thr for all k of the launch;
     // eps_out[workgroup] = +inf if any wavefront of the workgroup did, else 0.
+    // EPS == 3: witness for sweeps 0 .. T-2 (word eps_out[workgroup]) and the exact Eps of the LAST sweep
+    // (word eps_out[eps_stride + workgroup]): what the final launch of an ITER|EPS solve needs -- "no early
+    // stop before the budget" plus last_eps -- at the price of one measured sweep instead of T.
     // `stamps` is a diagnostic buffer (NULL in production: no stamp executes).  When set, lane 0 of
     // wavefront 0 records shader-clock / 100 MHz wall-clock stamps at the phase boundaries into
     // memory nothing else reads (HSFLOW_DEBUG_STAMPS, see hs_runtime.hip.h).
@@ -297,9 +311,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (rdist[r] <= g.T - 1 - s) {                                                             \
             const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
             strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF);    \
-            if (EPS) {                                                                             \
+            if (EM) {                                                                              \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
-                    if (EPS == 1) {                                                                \
+                    if (EM == 1) {                                                                 \
                         const f2 dUP = ouP - uP[r], dUQ = ouQ - uQ[r], dVP = ovP - vP[r], dVQ = ovQ - vQ[r]; \
                         if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
                             e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                       \
@@ -354,8 +368,11 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
     int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
                     // loop-carried flag makes the register allocator spill inside the loop)
-#pragma unroll 1
-    for (int s = 0; s < g.T; s++) {
+    // One sweep.  EM is the Eps mode of THIS sweep: the launch's own (EPS 0, 1, 2), or for EPS == 3 witness
+    // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
+    // loop, so that the loop keeps the registers of the witness kernel.
+    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
+        constexpr int EM = decltype(em_tag)::value;
 #if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
 #else
@@ -391,7 +408,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
             if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
             else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
-            if (EPS == 2 || s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
+            if (EM == 2 || s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
             f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
@@ -402,8 +419,12 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
             }
         }
-        if (R == 1 && (EPS == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
-        if (EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
+        if (R == 1 && (EM == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
+        if (EM == 1 && EPS == 3) { // the one measured sweep of a witness launch: folded after the loop
+            e = wave_max_nonneg(lanecore ? e : 0.f);
+            if (lane == 0) eps_lds[16 + w] = e;
+        }
+        if (EM == 1 && EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
             e = wave_max_nonneg(lanecore ? e : 0.f);
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
@@ -412,7 +433,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
             }
         }
-        if (EPS == 2 && (rowcore & 1u)) {
+        if (EM == 2 && (rowcore & 1u)) {
             // witness, read back from the exchange buffers at the end of the sweep (no register is kept
             // for it): slot 0 of this wavefront holds its first row of u, new in buffer (s+1)&1 and old
             // in buffer s&1; component x is column x0, an image column wherever lanecore holds
@@ -423,6 +444,18 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (!P2P && s + 1 < g.T) __syncthreads();
 #endif
+    };
+    if constexpr (EPS == 3) {
+#pragma unroll 1
+        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, 2>{});
+        sweep(g.T - 1, std::integral_constant<int, 1>{});
+    } else if constexpr (HS_PEEL_LAST_STRIP && EPS != 1) {
+#pragma unroll 1
+        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
+        sweep(g.T - 1, std::integral_constant<int, EPS>{});
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
     }
     if (EPS == 1) {
         __syncthreads();
@@ -432,12 +465,17 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
         }
     }
-    if (EPS == 2) {
-        if (lane == 0) eps_lds[w] = (seen_n == g.T && (rowcore & 1u)) ? __builtin_inff() : 0.f;
+    if (EPS == 2 || EPS == 3) {
+        const int witnessed = EPS == 3 ? g.T - 1 : g.T; // sweeps that ran in witness mode
+        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & 1u)) ? __builtin_inff() : 0.f;
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
             if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
+            if (EPS == 3) { // second word: Eps of the last sweep, exact
+                const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
+                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
+            }
         }
     }
 #undef HS_ROW
@@ -648,7 +686,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         if (rdist[r] <= g.T - 1 - s) {                                                             \
             const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
             strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
-            if (EPS == 1) {                                                                        \
+            if (EM == 1) {                                                                         \
                 if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
                     e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
                     if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
@@ -677,8 +715,9 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     const int wo = lower ? (w < NW - 1 ? w + 1 : w) : (w > 0 ? w - 1 : w);
     const int ho = lower ? (w < NW - 1 ? 0 : 1) : (w > 0 ? 1 : 0);
     int seen_n = 0; // EPS == 2: sweeps in which some lane of this wavefront saw a change >= eps_thr
-#pragma unroll 1
-    for (int s = 0; s < g.T; s++) {
+    // one sweep in Eps mode EM (k_jacobi_strip explains EPS == 3: witness sweeps, then one measured sweep)
+    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
+        constexpr int EM = decltype(em_tag)::value;
         const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
         const float4 h4u = eo[0], h4v = eo[32];
         const f2 ouP_ = f2{h4u.x, h4u.y}, ouQ_ = f2{h4u.z, h4u.w}, ovP_ = f2{h4v.x, h4v.y}, ovQ_ = f2{h4v.z, h4v.w};
@@ -697,7 +736,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             constexpr int R1 = R > 1 ? 1 : 0;
             HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
         }
-        if (EPS == 2 || s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+        if (EM == 2 || s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
 #pragma unroll
         for (int r = 1; r < R; r++) {
             const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
@@ -706,14 +745,18 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
             puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
         }
-        if (EPS == 2) {
+        if (EM == 2) {
             // witness (k_jacobi_strip explains it): old and new value of the published row -- register
             // row 0 of each half -- at column x0 come back from the two exchange buffers
             const float nu = *(const float *)(HF_SLOT((s + 1) & 1, w, lower ? 1 : 0) + hl);
             const float ou = *(const float *)(HF_SLOT(s & 1, w, lower ? 1 : 0) + hl);
             seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
         }
-        if (EPS == 1) {
+        if (EM == 1 && EPS == 3) {
+            e = wave_max(e);
+            if (lane == 0) eps_lds[16 + w] = e;
+        }
+        if (EM == 1 && EPS == 1) {
             e = wave_max(e);
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
@@ -723,6 +766,18 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             }
         }
         if (s + 1 < g.T) __syncthreads();
+    };
+    if constexpr (EPS == 3) {
+#pragma unroll 1
+        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, 2>{});
+        sweep(g.T - 1, std::integral_constant<int, 1>{});
+    } else if constexpr (HS_PEEL_LAST_FOLD && EPS != 1) {
+#pragma unroll 1
+        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
+        sweep(g.T - 1, std::integral_constant<int, EPS>{});
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
     }
     if (EPS == 1) {
         __syncthreads();
@@ -732,12 +787,16 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
         }
     }
-    if (EPS == 2) {
-        if (lane == 0) eps_lds[w] = seen_n == g.T ? __builtin_inff() : 0.f;
+    if (EPS == 2 || EPS == 3) {
+        if (lane == 0) eps_lds[w] = seen_n == (EPS == 3 ? g.T - 1 : g.T) ? __builtin_inff() : 0.f;
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
             if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
+            if (EPS == 3) { // second word: Eps of the last sweep, exact
+                const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
+                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
+            }
         }
     }
 #undef HF_ROW

@@ -318,7 +318,8 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
     return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
 }
 
-// eps: 0 none, 1 Eps of every sweep, 2 witness (strip kernel only: one lower bound per launch)
+// eps: 0 none, 1 Eps of every sweep, 2 witness (strip / fold: one lower bound per launch), 3 witness + the exact Eps
+// of the last sweep (two words per workgroup)
 // deriv: this launch also does the derivative pass (only where strip_deriv_fusable() said so)
 hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *ui, const float *vi,
                     float *uo, float *vo, float coeff, bool cfg = false, int zero_in = 0, bool deriv = false)
@@ -326,6 +327,12 @@ hipError_t launch_j(const hsflow_ctx *c, const JPlan &pl, int eps, const float *
     if (pl.kind == HSFLOW_KERNEL_STRIP || pl.kind == HSFLOW_KERNEL_FOLD) {
         StripPlan sp = pl.s;
         sp.g.zero_in = zero_in;
+        if (eps == 3) { // witness + exact Eps of the last sweep
+            if (sp.fold) return deriv ? launch_strip_deriv_e<3, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                                      : launch_strip_e<3, true>(c, sp, ui, vi, uo, vo, coeff, cfg);
+            return deriv ? launch_strip_deriv_e<3, false>(c, sp, ui, vi, uo, vo, coeff, cfg)
+                         : launch_strip_e<3, false>(c, sp, ui, vi, uo, vo, coeff, cfg);
+        }
         if (deriv && sp.fold) return eps == 2 ? launch_strip_deriv_e<2, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
                                      : eps  ? launch_strip_deriv_e<1, true>(c, sp, ui, vi, uo, vo, coeff, cfg)
                                             : launch_strip_deriv_e<0, true>(c, sp, ui, vi, uo, vo, coeff, cfg);

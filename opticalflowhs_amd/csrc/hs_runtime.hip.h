@@ -6,15 +6,20 @@ namespace {
 // The graph cache is keyed by everything a captured launch sequence depends on (sizes, kernel shape,
 // lambda, epsilon ...); a caller that varies those from call to call must not grow it without bound.
 constexpr size_t kMaxGraphs = 32;
-void trim_graph_cache(hsflow_ctx *c)
+void drop_graphs(hsflow_ctx *c)
 {
-    if (c->graphs.size() < kMaxGraphs) return;
+    if (c->graphs.empty()) return;
     hipStreamSynchronize(c->stream); // no replay of an old graph may still be running
     for (auto &kv : c->graphs) {
         if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) hipGraphDestroy(kv.second.graph);
     }
     c->graphs.clear();
+}
+
+void trim_graph_cache(hsflow_ctx *c)
+{
+    if (c->graphs.size() >= kMaxGraphs) drop_graphs(c);
 }
 
 int check_ctx(hsflow_ctx *c, int pair)
@@ -111,30 +116,27 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
 }
 
 // Eps bookkeeping of an EPS-terminated solve: `sweeps` rows of `stride` words, cleared, plus the
-// reduction of the rows into dEpsAll[0..sweeps).
+// reduction of the rows into hEps[0..sweeps).
 // Buffers for `sweeps` Eps words of `stride` workgroups each (device) and their host copy; allocation
 // only, so that what follows can be captured in a graph.
 int eps_reserve(hsflow_ctx *c, int sweeps, int stride)
 {
     const size_t need = (size_t)sweeps * stride;
     if (c->epsTilesCap < need) {
+        drop_graphs(c); // captured launches hold the old address (this also waits for the stream)
         hipFree(c->dEpsTiles);
         c->dEpsTiles = nullptr; c->epsTilesCap = 0;
         HS_HIP(c, hipMalloc((void **)&c->dEpsTiles, need * sizeof(unsigned)));
         c->epsTilesCap = need;
     }
-    if (c->epsAllCap < sweeps) {
-        hipFree(c->dEpsAll);
-        c->dEpsAll = nullptr; c->epsAllCap = 0;
-        HS_HIP(c, hipMalloc((void **)&c->dEpsAll, (size_t)sweeps * sizeof(unsigned)));
-        c->epsAllCap = sweeps;
-    }
     if (c->hEpsCap < (size_t)sweeps) {
+        drop_graphs(c);
         HS_HIP(c, hipStreamSynchronize(c->stream)); // nothing in flight may still write the old buffer
         if (c->hEps) hipHostFree(c->hEps);
-        c->hEps = nullptr; c->hEpsCap = 0;
+        c->hEps = c->hEpsDev = nullptr; c->hEpsCap = 0;
         const size_t cap = std::max<size_t>(256, (size_t)sweeps * 2);
-        HS_HIP(c, hipHostMalloc((void **)&c->hEps, cap * sizeof(unsigned), hipHostMallocDefault));
+        HS_HIP(c, hipHostMalloc((void **)&c->hEps, cap * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+        HS_HIP(c, hipHostGetDevicePointer((void **)&c->hEpsDev, c->hEps, 0));
         c->hEpsCap = cap;
     }
     c->epsStride = stride;
@@ -153,11 +155,14 @@ int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
     return st ? st : eps_clear(c, sweeps, stride);
 }
 
-int eps_collect_enqueue(hsflow_ctx *c, int sweeps) // buffers from eps_reserve; nothing allocated here
+// Reduces the rows of per-workgroup words to one word per row, straight into the host's buffer (no copy
+// node).  Rows [0, n_first) hold cnt_first valid words, the others cnt_last (defaults: every row is
+// epsStride words, which then must have been cleared where a launch had fewer workgroups).
+int eps_collect_enqueue(hsflow_ctx *c, int sweeps, int n_first = 0, int cnt_first = 0, int cnt_last = -1)
 {
-    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->dEpsAll);
+    hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->hEpsDev,
+                       n_first, cnt_first, cnt_last < 0 ? c->epsStride : cnt_last);
     HS_HIP(c, hipGetLastError());
-    HS_HIP(c, hipMemcpyAsync(c->hEps, c->dEpsAll, (size_t)sweeps * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->epsPtr = c->dEps;
     c->epsStride = 1;
     return HSFLOW_OK;

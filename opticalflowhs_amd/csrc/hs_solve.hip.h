@@ -261,17 +261,18 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
     if (witness) {
         // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
         // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
-        // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch measures every
-        // sweep (it also provides last_eps).  If every bound holds and no sweep of the last launch
-        // but possibly its final one fell below epsilon, the early stop cannot have fired before the
-        // budget ran out and the result stands.  Otherwise (a flat or converged input) the exact
+        // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch also provides
+        // last_eps: it witnesses its sweeps but measures the final one.  If every bound holds and no sweep but possibly the final one fell below
+        // epsilon, the early stop cannot have fired before the budget ran out and the result stands.  Otherwise (a flat or converged input) the exact
         // per-sweep path below starts over from the saved flow.
         // threshold as the smallest float >= epsilon: "change >= epsThr" then implies "Eps >= epsilon"
         c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
         if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
         const int n_launch = (iters + T - 1) / T;
         const int last_chunk = iters - (n_launch - 1) * T;
-        const int slots = (n_launch - 1) + last_chunk;
+        // the last launch witnesses all its sweeps but the final one and measures that one (mode 3, two words)
+        const int last_mode = 3;
+        const int slots = (n_launch - 1) + 2;
         if ((st = eps_reserve(c, slots, stride))) return st;
         const int cur0 = c->cur;
         // the first launch also does the derivative pass where the kernel can (hs_plan_launch.hip.h)
@@ -282,8 +283,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         auto enqueue = [&]() -> int {
             int e0 = save_start();
             if (e0) return e0;
-            c->epsStride = stride;
-            if ((e0 = eps_clear(c, slots, stride))) return e0;
+            c->epsStride = stride; // (no clearing: every launch writes all its words, the reduction reads only those)
             bool fuse = fuse_deriv;
             if (do_deriv && !fuse) {
                 prof.begin(0);
@@ -298,7 +298,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 const int a = c->cur, b = a ^ 1;
                 c->epsPtr = c->dEpsTiles + (size_t)L * stride;
                 prof.begin(1);
-                hipError_t e = launch_j(c, cp, is_last ? 1 : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w, fuse);
+                hipError_t e = launch_j(c, cp, is_last ? last_mode : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w, fuse);
                 prof.end();
                 HS_HIP(c, e);
                 c->cur = b;
@@ -306,16 +306,17 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 fuse = false;
                 launches++;
             }
-            return eps_collect_enqueue(c, slots);
+            return eps_collect_enqueue(c, slots, n_launch - 1, plan_eps_stride(kernel, plan),
+                                       plan_eps_stride(kernel, last_chunk != T ? tailp : plan));
         };
         if (p.use_graph && !p.profile) {
             GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                          c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff, c->epsThr};
             auto configure = [&]() -> int {
                 HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
-                HS_HIP(c, launch_j(c, plan, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
-                if (has_tail) HS_HIP(c, launch_j(c, tailp, 1, nullptr, nullptr, nullptr, nullptr, coeff, true));
-                if (fuse_deriv) HS_HIP(c, launch_j(c, firstp, n_launch == 1 ? 1 : 2, nullptr, nullptr, nullptr, nullptr, coeff, true, 0, true));
+                HS_HIP(c, launch_j(c, plan, last_mode, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (has_tail) HS_HIP(c, launch_j(c, tailp, last_mode, nullptr, nullptr, nullptr, nullptr, coeff, true));
+                if (fuse_deriv) HS_HIP(c, launch_j(c, firstp, n_launch == 1 ? last_mode : 2, nullptr, nullptr, nullptr, nullptr, coeff, true, 0, true));
                 return HSFLOW_OK;
             };
             auto enqueue_n = [&](int *n) -> int {

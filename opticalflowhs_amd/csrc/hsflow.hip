@@ -171,7 +171,7 @@ int hsflow_destroy(hsflow_ctx *c)
     for (int i = 0; i < 3; i++) hipFree(c->dE[i]);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
-    hipFree(c->dEpsAll); hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
+    hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
     hipFree(c->dScratch);
     if (c->hEps) hipHostFree(c->hEps);

@@ -480,6 +480,14 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
         assert np.array_equal(u0, u1) and np.array_equal(v0, v1)
         assert abs(fast["last_eps"] - e_o) <= 1e-3 * e_o
         check("iter_eps_witness", (u1, v1), (uo, vo))
+        # last_eps: the strip kernel measures only the final sweep of its last launch (the others are witnessed),
+        # the folded kernel every sweep of the last launch, the single-sweep kernel every sweep: the same number
+        for k in (hs.KERNEL_FOLD, hs.KERNEL_SIMPLE, hs.KERNEL_FUSED):
+            other = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, kernel=k)
+            assert other["iterations_done"] == it and other["last_eps"] == fast["last_eps"], (k, other, fast)
+        for T in (1, 2, 19, 57):   # last launch of 1 sweep (nothing witnessed), tails, a single launch
+            r = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, kernel=hs.KERNEL_STRIP, fuse_steps=min(T, 24))
+            assert r["iterations_done"] == it and r["eps_rerun"] == 0 and r["last_eps"] == fast["last_eps"], (T, r)
         # epsilon just under the final Eps: whether or not the sampled lower bounds still clear it (if
         # not, every sweep gets measured), the answer stays "budget reached"
         for frac in (0.98, 0.999, 0.99999):
@@ -511,6 +519,25 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
         assert stop["jacobi_launches"] > plain["jacobi_launches"]          # witness pass + exact pass + re-run
         if stop["iterations_done"] == n3:
             check("iter_eps_early_stop", (u3, v3), (uo3, vo3))
+
+
+def test_cached_graphs_survive_growing_eps_buffers(hs, gpu_ok):
+    """An ITER|EPS graph captured with small Eps buffers, then a solve that makes those buffers grow (more
+    sweeps, more workgroups), then the first graph again: its replay must not use the freed buffers."""
+    W, H = 640, 360
+    A, B = synth.smooth_random_pair(W, H, seed=12, shift=(1, 0))
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        want = {}
+        for it in (12, 700, 40):
+            i = ctx.solve(lam=0.7, max_iter=it, term_type=ITER | EPS, epsilon=1e-7)
+            want[it] = ctx.flow() + (i["iterations_done"], i["last_eps"])
+        for rnd in range(3):
+            for it in (12, 700, 12, 40, 700, 12):
+                i = ctx.solve(lam=0.7, max_iter=it, term_type=ITER | EPS, epsilon=1e-7, use_graph=True)
+                u, v = ctx.flow()
+                assert np.array_equal(u, want[it][0]) and np.array_equal(v, want[it][1]), (rnd, it)
+                assert (i["iterations_done"], i["last_eps"]) == want[it][2:], (rnd, it, i)
 
 
 def test_graph_cache_stays_bounded(hs, oracle, gpu_ok):
