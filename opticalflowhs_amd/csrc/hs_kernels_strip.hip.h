@@ -107,8 +107,8 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
 // flip is undone here because the halo wants the mirrored pixel's coefficients unchanged.  The column
 // neighbours x0-1 and x0+4 come from the adjacent lanes (the region is contiguous in the reflected image);
 // lanes 0 and 63 have none, so the region's outermost columns get a wrong Ix -- they are invalid after the
-// first sweep anyway (HX >= T >= 1).  Host-side conditions (launch_j): W % 4 == 0 and the image at least as
-// large as the region, so a group is wholly inside or wholly mirrored and one bounce suffices.
+// first sweep anyway (HX >= T >= 1).  Host-side condition (strip_deriv_fusable): the image is at least as
+// large as the region, so that one bounce suffices.
 // Register row r of the lane is image row y0 + dir * r (dir = -1: the folded kernel's lower half, whose
 // registers run bottom-up).
 template <int R>
@@ -116,16 +116,53 @@ __device__ __forceinline__ void strip_derive(const uint8_t *__restrict__ fA, con
                                              const StripGeom &g, long long base, int x0, int y0, int dir, bool xin,
                                              uint4 (&lc)[R])
 {
-    int xg = x0;
-    if (!xin) {
+    // How this lane reads its four columns of a frame row: 0 an aligned word (group inside the image), 1 an
+    // aligned word read backwards (group wholly mirrored: left of the image, or right of it when W % 4 == 0),
+    // 2 four reflected bytes (W % 4 != 0: the group that straddles column W-1 and those right of it).
+    const int mode = xin ? 0 : ((x0 < 0 || (g.W & 3) == 0) ? 1 : 2);
+    int xg = x0, xb[4] = {0, 0, 0, 0};
+    unsigned flipx = 0; // pixels of the group that are mirrored columns: their Ix changes sign
+    if (mode == 1) {
         xg = x0 < 0 ? -x0 - 4 : 2 * g.W - x0 - 4;
         if (xg < 0 || xg + 4 > g.W) xg = 0; // excluded by the host; keeps the load inside the row regardless
+        flipx = 0xFu;
+    } else if (mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            xb[k] = mirror_index(x0 + k, g.W);
+            if (x0 + k >= g.W) flipx |= 1u << k;
+        }
+    }
+    // All word loads first, branch-free (mode 2 lanes read a harmless aligned word), so that they overlap;
+    // then ONE wave-uniform branch in which the mode 2 lanes -- if the wavefront has any -- fetch their bytes.
+    uint32_t wa[R + 2], wbv[R];
+#pragma unroll
+    for (int j = 0; j < R + 2; j++)
+        wa[j] = *(const uint32_t *)(fA + base + (long long)mirror_index(y0 + dir * (j - 1), g.H) * g.P + (mode == 2 ? 0 : xg));
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        wbv[r] = *(const uint32_t *)(fB + base + (long long)mirror_index(y0 + dir * r, g.H) * g.P + (mode == 2 ? 0 : xg));
+    if (mode == 1) {
+#pragma unroll
+        for (int j = 0; j < R + 2; j++) wa[j] = __builtin_bswap32(wa[j]);
+#pragma unroll
+        for (int r = 0; r < R; r++) wbv[r] = __builtin_bswap32(wbv[r]);
+    }
+    if (__builtin_amdgcn_ballot_w64(mode == 2) != 0) {
+        if (mode == 2) {
+            auto bytes = [&](const uint8_t *row) -> uint32_t {
+                return (uint32_t)row[xb[0]] | ((uint32_t)row[xb[1]] << 8) | ((uint32_t)row[xb[2]] << 16) | ((uint32_t)row[xb[3]] << 24);
+            };
+#pragma unroll
+            for (int j = 0; j < R + 2; j++) wa[j] = bytes(fA + base + (long long)mirror_index(y0 + dir * (j - 1), g.H) * g.P);
+#pragma unroll
+            for (int r = 0; r < R; r++) wbv[r] = bytes(fB + base + (long long)mirror_index(y0 + dir * r, g.H) * g.P);
+        }
     }
     int a[R + 2][6]; // columns x0-1 .. x0+4 of the reflected rows y0 - dir, y0, ..., y0 + dir * R
 #pragma unroll
     for (int j = 0; j < R + 2; j++) {
-        uint32_t wd = *(const uint32_t *)(fA + base + (long long)mirror_index(y0 + dir * (j - 1), g.H) * g.P + xg);
-        if (!xin) wd = __builtin_bswap32(wd);
+        const uint32_t wd = wa[j];
         a[j][0] = (int)((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd, 0x138, 0xF, 0xF, true) >> 24);
         a[j][5] = (int)((uint32_t)__builtin_amdgcn_update_dpp(0, (int)wd, 0x130, 0xF, 0xF, true) & 0xFFu);
 #pragma unroll
@@ -134,15 +171,14 @@ __device__ __forceinline__ void strip_derive(const uint8_t *__restrict__ fA, con
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int y = y0 + dir * r;
-        uint32_t wb = *(const uint32_t *)(fB + base + (long long)mirror_index(y, g.H) * g.P + xg);
-        if (!xin) wb = __builtin_bswap32(wb);
+        const uint32_t wb = wbv[r];
         const bool yflip = (y < 0 || y >= g.H) != (dir < 0); // a[r + 2] is the row BELOW only when dir > 0
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int ix8 = (a[r][k + 2] + 2 * a[r + 1][k + 2] + a[r + 2][k + 2]) - (a[r][k] + 2 * a[r + 1][k] + a[r + 2][k]);
             int iy8 = (a[r + 2][k] + 2 * a[r + 2][k + 1] + a[r + 2][k + 2]) - (a[r][k] + 2 * a[r][k + 1] + a[r][k + 2]);
-            if (!xin) ix8 = -ix8;
+            if ((flipx >> k) & 1u) ix8 = -ix8;
             if (yflip) iy8 = -iy8;
             o[k] = pack_deriv(ix8, iy8, (int)((wb >> (8 * k)) & 0xFFu) - a[r + 1][k + 1]);
         }

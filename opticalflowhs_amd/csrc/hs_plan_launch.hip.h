@@ -298,15 +298,15 @@ hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const f
 }
 
 // Can the first launch of a solve compute the derivatives itself (k_jacobi_strip_deriv / k_jacobi_fold_deriv)?
-// The kernels' reflection argument wants whole 4-pixel groups inside or outside the image and a single
-// bounce: an image at least as large as one workgroup's region (256 or 128 columns x all its rows).
+// The kernels' reflection argument wants a single bounce: an image at least as large as one workgroup's
+// region (256 or 128 columns x all its rows).
 bool strip_deriv_fusable(const hsflow_ctx *c, const JPlan &pl)
 {
     static const bool off = getenv("HSFLOW_NO_DERIV_FUSION") != nullptr;
     if (off || (pl.kind != HSFLOW_KERNEL_STRIP && pl.kind != HSFLOW_KERNEL_FOLD)) return false;
     if (pl.s.R < 1 || pl.s.R > 6) return false; // 7 and 8 rows per lane: not instantiated
     const int region_w = pl.s.fold ? 128 : 256, region_h = pl.s.g.NW * pl.s.R * (pl.s.fold ? 2 : 1);
-    return (c->W & 3) == 0 && c->W >= region_w && c->H >= region_h;
+    return c->W >= region_w && c->H >= region_h;
 }
 
 bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)
