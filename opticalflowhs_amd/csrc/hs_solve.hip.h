@@ -515,7 +515,10 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
     if (async && p.profile) return fail(c, HSFLOW_E_ARG, "solve_async does not support profiling");
 
-    const float coeff = 1.0f / p.lambda; // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085
+    // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085.  Kept out of the denormal range
+    // (lambda > 8.5e37): v_rsq_f32 in sweep_coefs flushes denormals, and where it matters -- a pixel with
+    // Ix = Iy = 0 -- any finite value gives the same update (al = be = 0).
+    const float coeff = std::max(1.0f / p.lambda, FLT_MIN);
     // AUTO: the register-strip kernel; below ~1.5 Mpixel per context its folded form (128-column strips:
     // twice the tiles across, so small frames reach more CUs -- measured 5-25 % faster from 160x120 to
     // 1600x900 at 100 sweeps, tools/crossover.py).

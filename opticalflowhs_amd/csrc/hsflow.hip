@@ -11,6 +11,7 @@
 #include "hs_kernels_classic.hip.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): everything the numbers in DESIGN.md section 6 and profiles/ are quoted from.
+# Outputs under gpurun_out/refresh/ ; copy into profiles/ with the names profiles/README.md lists.
+# usage: tools/refresh_profiles.sh [tag]          (default tag r01)
+set -o pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/refresh
+mkdir -p "$OUT"
+cd "$ROOT"
+run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
+run python bench.py > "$OUT/bench_1080p.json" 2> "$OUT/bench_1080p.err" || exit 1
+run python bench.py --iter-eps --skip-cpu > "$OUT/bench_1080p_itereps.json" 2>> "$OUT/err.txt" || exit 2
+run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5 --skip-cpu > "$OUT/bench_4k.json" 2>> "$OUT/err.txt" || exit 3
+{
+  echo "# 16 pairs per step (C4 shard of one GPU)";      run python bench.py --pairs 16 --steps 30 --warmup 5 --skip-cpu 2>> "$OUT/err.txt" || exit 4
+  echo "# 16384 x 2048 strip (C5 slab of one GPU), 100 it"; run python bench.py --width 16384 --height 2048 --iters 100 --steps 10 --warmup 2 --skip-cpu 2>> "$OUT/err.txt" || exit 5
+  echo "# simple kernel, 1080p";                           run python bench.py --kernel simple --steps 30 --warmup 5 --skip-cpu 2>> "$OUT/err.txt" || exit 6
+  echo "# simple kernel, 4K/200";                          run python bench.py --kernel simple --width 3840 --height 2160 --iters 200 --steps 10 --warmup 2 --skip-cpu 2>> "$OUT/err.txt" || exit 7
+  echo "# slab driver, one rank, 16384 x 2048, 100 it, halo 16 (tools/bench_slab.py)"
+  run python tools/bench_slab.py --width 16384 --height 2048 --iters 100 --halo 16 --steps 3 2>> "$OUT/err.txt" || exit 8
+} > "$OUT/bench_misc.txt"
+run python tools/bench_classic.py > "$OUT/bench_classic.txt" 2>> "$OUT/err.txt" || exit 9
+run python tools/bench_e2e.py > "$OUT/e2e_pipeline.txt" 2>> "$OUT/err.txt" || exit 10
+{ run python tools/crossover.py 100; run python tools/crossover.py 10; } > "$OUT/crossover.txt" 2>> "$OUT/err.txt" || exit 11
+run python tools/time_cases.py > "$OUT/time_cases.txt" 2>> "$OUT/err.txt" || exit 12
+run bash tools/profile_gpu.sh "$TAG" > "$OUT/prof.log" 2>&1 || exit 13
+run bash tools/profile_gpu.sh "${TAG}_4k" --width 3840 --height 2160 --iters 200 > "$OUT/prof_4k.log" 2>&1 || exit 14
+echo done
