@@ -262,16 +262,16 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost
         // nothing over the ITER-only kernel and yields one number per launch that proves "Eps >=
         // epsilon in every one of my sweeps" when it is >= epsilon.  The last launch also provides
-        // last_eps: it witnesses its sweeps but measures the final one.  If every bound holds and no sweep but possibly the final one fell below
-        // epsilon, the early stop cannot have fired before the budget ran out and the result stands.  Otherwise (a flat or converged input) the exact
-        // per-sweep path below starts over from the saved flow.
+        // last_eps: it witnesses its sweeps but measures the final one (mode 3).  If every bound
+        // holds, the early stop cannot have fired before the budget ran out (a stop AT the final
+        // sweep is the budget) and the result stands.  Otherwise (a flat or converged input) the
+        // exact per-sweep path below starts over from the saved flow.
         // threshold as the smallest float >= epsilon: "change >= epsThr" then implies "Eps >= epsilon"
         c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
         if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
         const int n_launch = (iters + T - 1) / T;
         const int last_chunk = iters - (n_launch - 1) * T;
-        // the last launch witnesses all its sweeps but the final one and measures that one (mode 3, two words)
-        const int last_mode = 3;
+        const int last_mode = 3; // two words per workgroup: the witness and the final sweep's Eps
         const int slots = (n_launch - 1) + 2;
         if ((st = eps_reserve(c, slots, stride))) return st;
         const int cur0 = c->cur;
