@@ -217,6 +217,30 @@ def main():
             out["roofline"]["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9  # what HBM physically moves
             break
 
+    # the roofline fraction also against what a plain device-to-device copy reaches on this box
+    # (1 GiB read + 1 GiB written per copy, torch's copy kernel, HIP events on torch's stream)
+    if rank == 0:
+        try:
+            n = 1 << 28  # floats
+            src = torch.empty(n, dtype=torch.float32, device="cuda")
+            dst = torch.empty_like(src)
+            src.fill_(1.0)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 10
+            for _ in range(reps):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            out["roofline"]["measured_copy_GBps"] = copy_gbps
+            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbps
+            del src, dst
+        except RuntimeError:
+            pass
+
     if rank == 0 and world == 1 and not args.skip_cpu:
         from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
         hs_oracle.build()
