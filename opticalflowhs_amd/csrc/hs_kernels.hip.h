@@ -15,7 +15,8 @@
 //     drops by ~T, the sweep itself runs out of LDS + registers;
 //   * wavefront (64-lane) DPP shifts fetch the left/right neighbours held by adjacent lanes.
 // All arithmetic is fp32 with explicit fmaf; the file is compiled with -ffp-contract=off so that
-// every kernel variant produces bit-identical flow (tests rely on that).
+// every kernel variant produces bit-identical flow (tests rely on that; the strip kernels' scaled state,
+// hs_kernels_strip.hip.h, keeps it down to the edge of the denormal range).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -6,6 +6,15 @@
 // Last sweep of a launch as a second copy of the sweep code after the loop (the loop then publishes and
 // meets the barrier unconditionally).  Folded kernel: far fewer spills (R = 4: 33 -> 7, R = 5: 33 -> 1) and
 // 15 VGPRs less at R = 3; strip kernel: slightly worse (R = 5 / 16 wavefronts: 2 -> 11 spills), so not there.
+// Scaled state: inside a launch the flow is carried as 4^k * u after k sweeps, so that the neighbour SUM is
+// the average at the next scale and the multiplication by 0.25 disappears (the constant term ga is rescaled
+// instead: one packed multiply per pair of pixels where there were two).  Powers of 4 commute with every
+// rounding, so the result is bit-identical to the canonical arithmetic of update_cv<> -- except for values that
+// would be denormal there (below 1.2e-38), which keep their bits here.  T <= 24: 4^24 = 2.8e14, no overflow for
+// any flow a valid lambda allows.
+#ifndef HS_SCALED
+#define HS_SCALED 1
+#endif
 #ifndef HS_PEEL_LAST_STRIP
 #define HS_PEEL_LAST_STRIP 0
 #endif
@@ -64,6 +73,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+// old - new of a sweep, in the NEW value's scale (HS_SCALED: the old one is a factor 4 behind)
+#if HS_SCALED
+#define HS_DIFF(o, n) f2_fma((o), f2{4.0f, 4.0f}, -(n))
+#define HS_DIFF1(o, n) fmaf(4.0f, (o), -(n))
+#else
+#define HS_DIFF(o, n) ((o) - (n))
+#define HS_DIFF1(o, n) ((o) - (n))
+#endif
 
 // One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs, so that every
 // arithmetic step except the four side-neighbour additions is a packed (2 pixels per
@@ -73,7 +90,7 @@ struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
 
 __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const f2 upuP, const f2 upuQ,
                                                  const f2 upvP, const f2 upvQ, const f2 dnuP, const f2 dnuQ,
-                                                 const f2 dnvP, const f2 dnvQ, const RowCoef &c)
+                                                 const f2 dnvP, const f2 dnvQ, RowCoef &c)
 {
     // u plane
     f2 tP = f2_swap(uP) + (upuP + dnuP);
@@ -82,7 +99,11 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     tP.y += uQ.x;
     tQ.x += uP.y;
     tQ.y += wave_from_next_lane(uP.x);
+#if HS_SCALED
+    const f2 ubP = tP, ubQ = tQ; // 4^(k+1) * average
+#else
     const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f;
+#endif
     // v plane
     f2 sP = f2_swap(vP) + (upvP + dnvP);
     f2 sQ = f2_swap(vQ) + (upvQ + dnvQ);
@@ -90,7 +111,11 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     sP.y += vQ.x;
     sQ.x += vP.y;
     sQ.y += wave_from_next_lane(vP.x);
+#if HS_SCALED
+    const f2 vbP = sP, vbQ = sQ;
+#else
     const f2 vbP = sP * 0.25f, vbQ = sQ * 0.25f;
+#endif
     // update
     const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
     const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
@@ -98,6 +123,10 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     vP = f2_fma(-c.beP, qP, vbP);
     uQ = f2_fma(-c.alQ, qQ, ubQ);
     vQ = f2_fma(-c.beQ, qQ, vbQ);
+#if HS_SCALED
+    c.gaP *= 4.0f; // the constant term at the next sweep's scale
+    c.gaQ *= 4.0f;
+#endif
 }
 
 // The packed derivative words of a lane's R rows straight from the two frames (DERIV launches: the first
@@ -317,7 +346,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
         cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
         cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
+        cf[r].gaP = f2{ga[0], ga[1]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[2], ga[3]} * (HS_SCALED ? 4.0f : 1.0f);
     }
     // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
     unsigned rowcore = 0;
@@ -350,7 +379,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             if (EM) {                                                                              \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
                     if (EM == 1) {                                                                 \
-                        const f2 dUP = ouP - uP[r], dUQ = ouQ - uQ[r], dVP = ovP - vP[r], dVQ = ovQ - vQ[r]; \
+                        const f2 dUP = HS_DIFF(ouP, uP[r]), dUQ = HS_DIFF(ouQ, uQ[r]), dVP = HS_DIFF(ovP, vP[r]), dVQ = HS_DIFF(ovQ, vQ[r]); \
                         if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
                             e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                       \
                             e = fmaxf(fmaxf(e, fabsf(dUQ.x)), fabsf(dUQ.y));                       \
@@ -409,6 +438,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // loop, so that the loop keeps the registers of the witness kernel.
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
+        // HS_SCALED: this sweep takes the flow from scale 4^s to 4^(s+1)
+        const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
+        const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
 #if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
 #else
@@ -457,11 +489,11 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         }
         if (R == 1 && (EM == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
         if (EM == 1 && EPS == 3) { // the one measured sweep of a witness launch: folded after the loop
-            e = wave_max_nonneg(lanecore ? e : 0.f);
+            e = wave_max_nonneg(lanecore ? e : 0.f) * unscale;
             if (lane == 0) eps_lds[16 + w] = e;
         }
         if (EM == 1 && EPS == 1) { // per-wavefront maximum -> LDS; wavefront 0 folds the previous sweep's 16 values
-            e = wave_max_nonneg(lanecore ? e : 0.f);
+            e = wave_max_nonneg(lanecore ? e : 0.f) * unscale;
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
                 float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
@@ -475,7 +507,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             // in buffer s&1; component x is column x0, an image column wherever lanecore holds
             const float nu = *(const float *)(ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane);
             const float ou = *(const float *)(ex + ((size_t)((s & 1) * NW + w) * 4) * 64 + lane);
-            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
+            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(ou, nu)) >= thr_s) != 0 ? 1 : 0;
         }
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (!P2P && s + 1 < g.T) __syncthreads();
@@ -534,8 +566,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(u_out + off), "v"(su_) : "memory");
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(v_out + off), "v"(sv_) : "memory");
 #else
-                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
+                const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
+                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
 #endif
             }
         }
@@ -694,7 +727,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
         cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
         cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]}; cf[r].gaQ = f2{ga[2], ga[3]};
+        cf[r].gaP = f2{ga[0], ga[1]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[2], ga[3]} * (HS_SCALED ? 4.0f : 1.0f);
     }
     // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
     unsigned rowcore = 0;
@@ -724,10 +757,10 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
             if (EM == 1) {                                                                         \
                 if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
-                    e = fmaxf(e, fmaxf(fabsf(ouP.x - uP[r].x), fabsf(ovP.x - vP[r].x)));           \
-                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(ouP.y - uP[r].y), fabsf(ovP.y - vP[r].y))); \
-                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(ouQ.x - uQ[r].x), fabsf(ovQ.x - vQ[r].x))); \
-                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(ouQ.y - uQ[r].y), fabsf(ovQ.y - vQ[r].y))); \
+                    e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.x, uP[r].x)), fabsf(HS_DIFF1(ovP.x, vP[r].x))));           \
+                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.y, uP[r].y)), fabsf(HS_DIFF1(ovP.y, vP[r].y)))); \
+                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.x, uQ[r].x)), fabsf(HS_DIFF1(ovQ.x, vQ[r].x)))); \
+                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.y, uQ[r].y)), fabsf(HS_DIFF1(ovQ.y, vQ[r].y)))); \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -754,6 +787,8 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     // one sweep in Eps mode EM (k_jacobi_strip explains EPS == 3: witness sweeps, then one measured sweep)
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
+        const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
+        const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
         const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
         const float4 h4u = eo[0], h4v = eo[32];
         const f2 ouP_ = f2{h4u.x, h4u.y}, ouQ_ = f2{h4u.z, h4u.w}, ovP_ = f2{h4v.x, h4v.y}, ovQ_ = f2{h4v.z, h4v.w};
@@ -786,14 +821,14 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             // row 0 of each half -- at column x0 come back from the two exchange buffers
             const float nu = *(const float *)(HF_SLOT((s + 1) & 1, w, lower ? 1 : 0) + hl);
             const float ou = *(const float *)(HF_SLOT(s & 1, w, lower ? 1 : 0) + hl);
-            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(ou - nu) >= eps_thr) != 0 ? 1 : 0;
+            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(ou, nu)) >= thr_s) != 0 ? 1 : 0;
         }
         if (EM == 1 && EPS == 3) {
-            e = wave_max(e);
+            e = wave_max(e) * unscale;
             if (lane == 0) eps_lds[16 + w] = e;
         }
         if (EM == 1 && EPS == 1) {
-            e = wave_max(e);
+            e = wave_max(e) * unscale;
             if (lane == 0) eps_lds[(s & 1) * 16 + w] = e;
             if (s > 0 && w == 0) {
                 float x = lane < NW ? eps_lds[((s - 1) & 1) * 16 + lane] : 0.f;
@@ -846,8 +881,9 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             if ((rowcore >> r) & 1u) {
                 const int y = yb + (lower ? 2 * R - 1 - r : r);
                 const long long off = base + (long long)y * g.P + x0;
-                *(float4 *)(u_out + off) = make_float4(uP[r].x, uP[r].y, uQ[r].x, uQ[r].y);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x, vP[r].y, vQ[r].x, vQ[r].y);
+                const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
+                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
             }
         }
     }
