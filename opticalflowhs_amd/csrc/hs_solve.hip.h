@@ -546,6 +546,10 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
                                                           : pick_strip_T(c, horizon, p, kernel == HSFLOW_KERNEL_FOLD);
         else T = pick_T(horizon, 0);
         if (budget < T) T = (int)budget;
+        // The strip kernels carry 4^k * u inside a launch (hs_kernels_strip.hip.h).  The largest flow and
+        // constant term a pixel can have grow like sqrt(lambda); beyond lambda = 1e20 keep the launches
+        // short so that 4^(T+1) times those stays far inside the float range.
+        if ((kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && coeff < 1e-20f) T = std::min(T, 8);
         if (!make_jplan(c, kernel, T, p, plan))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the requested tile/threads/rows/fuse_steps");
         plan_to_info(c, plan);

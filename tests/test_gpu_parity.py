@@ -217,6 +217,17 @@ def test_scaled_state_matches_canonical_arithmetic_down_to_denormals(hs, gpu_ok)
                 assert np.array_equal(g[safe], r[safe]), (it, kern, kw)
                 assert np.all(np.abs(g[~safe].astype(np.float64) - r[~safe]) < 1e-41), (it, kern, kw)
         assert (np.abs(ref[0]) < tiny).any() and (np.abs(ref[0]) > 1e-3).any()   # both regimes are present
+    # enormous lambda: the flow and the constant term grow like sqrt(lambda); the scaled state must not overflow
+    # where the canonical arithmetic does not (launches are kept short beyond lambda = 1e20)
+    A, B = synth.random_pair(300, 200, seed=8)
+    for lam in (1e12, 1e19, 1e21, 1e30, 3e38):
+        ref = gpu_solve(hs, A, B, lam, 70, kernel=hs.KERNEL_SIMPLE)
+        for kern, kw in ((hs.KERNEL_STRIP, {}), (hs.KERNEL_FOLD, {}), (hs.KERNEL_STRIP, dict(fuse_steps=32)), (hs.KERNEL_FOLD, dict(fuse_steps=24))):
+            got = gpu_solve(hs, A, B, lam, 70, kernel=kern, **kw)
+            for g, r in ((got[0], ref[0]), (got[1], ref[1])):
+                fin = np.isfinite(r)
+                assert np.array_equal(np.isfinite(g), fin), (lam, kern, kw)
+                assert np.array_equal(g[fin], r[fin]), (lam, kern, kw, float(np.abs(r[fin]).max()))
 
 
 def test_eps_termination_matches_oracle(hs, gpu_ok):
