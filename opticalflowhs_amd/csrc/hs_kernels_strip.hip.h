@@ -15,6 +15,9 @@
 #ifndef HS_SCALED
 #define HS_SCALED 1
 #endif
+#ifndef HS_UNROLL2
+#define HS_UNROLL2 0
+#endif
 #ifndef HS_PEEL_LAST_STRIP
 #define HS_PEEL_LAST_STRIP 0
 #endif
@@ -521,6 +524,14 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #pragma unroll 1
         for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
         sweep(g.T - 1, std::integral_constant<int, EPS>{});
+    } else if constexpr (HS_UNROLL2 && EPS != 1) { // EXPERIMENT: two sweeps per loop trip
+        int s = 0;
+#pragma unroll 1
+        for (; s + 1 < g.T; s += 2) {
+            sweep(s, std::integral_constant<int, EPS>{});
+            sweep(s + 1, std::integral_constant<int, EPS>{});
+        }
+        if (s < g.T) sweep(s, std::integral_constant<int, EPS>{});
     } else {
 #pragma unroll 1
         for (int s = 0; s < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
