@@ -15,6 +15,9 @@
 #ifndef HS_SCALED
 #define HS_SCALED 1
 #endif
+#ifndef HS_UNROLL2_FOLD
+#define HS_UNROLL2_FOLD 1
+#endif
 #ifndef HS_UNROLL2
 #define HS_UNROLL2 0
 #endif
@@ -854,8 +857,16 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, 2>{});
         sweep(g.T - 1, std::integral_constant<int, 1>{});
     } else if constexpr (HS_PEEL_LAST_FOLD && EPS != 1) {
+        int s = 0;
+        if constexpr (HS_UNROLL2_FOLD) { // two sweeps per trip: the register copies at the loop's back edge halve
 #pragma unroll 1
-        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
+            for (; s + 2 < g.T; s += 2) {
+                sweep(s, std::integral_constant<int, EPS>{});
+                sweep(s + 1, std::integral_constant<int, EPS>{});
+            }
+        }
+#pragma unroll 1
+        for (; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
         sweep(g.T - 1, std::integral_constant<int, EPS>{});
     } else {
 #pragma unroll 1
