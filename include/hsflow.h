@@ -187,7 +187,8 @@ int hsflow_get_flow(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, float 
 int hsflow_get_flow_async(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, float *v, size_t v_stride);
 /* Row range [row0, row0+nrows) of the flow to / from device memory, on ctx's stream (used for
  * the row-slab halo exchange).  set_ writes into the flow the next
- * use_previous=1 solve continues from. */
+ * use_previous=1 solve continues from.  Both settle an ITER|EPS check that hsflow_solve_async still
+ * owes (they wait for the stream in that case); after an ITER-only solve they only enqueue. */
 int hsflow_get_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, void *d_u,
                            size_t u_stride, void *d_v, size_t v_stride);
 int hsflow_set_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, const void *d_u,

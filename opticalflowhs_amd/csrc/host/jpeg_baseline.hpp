@@ -264,8 +264,10 @@ inline bool decode(const std::vector<uint8_t> &file, pnm::Image &img, std::strin
                 h.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) { // SOF0 / SOF1 (extended sequential, Huffman, 8-bit only)
+            if (have_sof) return fail("more than one frame header");
             if (se - s < 6 || s[0] != 8) return fail("only 8-bit samples are supported");
             H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
+            hmax = vmax = 1;
             const int n = s[5];
             if (W <= 0 || H <= 0 || (long long)W * H > (1LL << 28) || (n != 1 && n != 3) || se - s < 6 + 3 * n)
                 return fail("unsupported frame header");
@@ -275,6 +277,7 @@ inline bool decode(const std::vector<uint8_t> &file, pnm::Image &img, std::strin
                 comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15;
                 comp[i].tq = s[8 + 3 * i];
                 if (comp[i].tq > 3) return fail("bad quantisation table index");
+                if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) return fail("bad sampling factor");
                 hmax = comp[i].h > hmax ? comp[i].h : hmax;
                 vmax = comp[i].v > vmax ? comp[i].v : vmax;
             }
@@ -286,6 +289,7 @@ inline bool decode(const std::vector<uint8_t> &file, pnm::Image &img, std::strin
             restart_interval = (s[0] << 8) | s[1];
         } else if (m == 0xDA) { // SOS: baseline has exactly one scan with all components interleaved
             if (!have_sof) return fail("scan before frame header");
+            if (se - s < 1) return fail("truncated scan header");
             const int n = s[0];
             if (n != (int)comp.size() || se - s < 1 + 2 * n + 3) return fail("unsupported scan layout");
             for (int i = 0; i < n; i++) {
@@ -354,6 +358,10 @@ inline bool decode(const std::vector<uint8_t> &file, pnm::Image &img, std::strin
                 return true;
             }
             const int cw = (W + comp[0].h - 1) / comp[0].h, ch = (H + comp[0].v - 1) / comp[0].v; // real chroma samples
+            // every plane must cover what the conversion below reads (a header that lies about sampling must not over-read)
+            if (comp[0].wblocks * 8 < W || comp[0].hblocks * 8 < H || comp[1].wblocks * 8 < cw || comp[1].hblocks * 8 < ch ||
+                comp[2].wblocks * 8 < cw || comp[2].hblocks * 8 < ch)
+                return fail("component planes smaller than the frame");
             std::vector<uint8_t> cb, cr;
             const uint8_t *pcb, *pcr;
             int cstride;

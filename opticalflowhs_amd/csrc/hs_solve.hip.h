@@ -454,6 +454,14 @@ int solve_eps_chunks(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S,
     int launches = 0;
     float last = 0.f;
     bool stop = false;
+    // Without a sweep budget the only exit is Eps < epsilon.  A positive epsilon below the fp32 limit cycle of
+    // the iteration (Eps stalls around 1e-7 * |flow|) would keep the host launching for ever -- the original
+    // does exactly that; here the solve gives up with HSFLOW_E_NOTERM (flow, iterations_done and last_eps
+    // stay valid) once Eps has not reached a new minimum for kStallSweeps sweeps or after kMaxSweeps.
+    constexpr long long kStallSweeps = 4096, kMaxSweeps = 1LL << 24;
+    float best_eps = INFINITY;
+    long long best_at = 0;
+    bool stalled = false;
     while (!stop) {
         const int chunk = (int)std::min<long long>(T, budget - done);
         JPlan cp = plan;
@@ -477,6 +485,7 @@ int solve_eps_chunks(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S,
             float e;
             std::memcpy(&e, &heps[(size_t)s], sizeof(float));
             last = e;
+            if (e < best_eps) { best_eps = e; best_at = done + s; }
             if ((double)e < p.epsilon) { hit = s; break; }
         }
         if (hit >= 0 && hit < n - 1) { // crossed inside the chunk: redo exactly hit+1 sweeps
@@ -495,12 +504,16 @@ int solve_eps_chunks(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S,
         }
         c->cur = b;
         if (use_iter && p.max_iter > 0 && done >= budget) stop = true;
+        if (!stop && budget > kMaxSweeps && (done - best_at >= kStallSweeps || done >= kMaxSweeps)) stop = stalled = true;
     }
     HS_HIP(c, hipStreamSynchronize(c->stream));
-    c->info.iterations_done = (int)done;
+    c->info.iterations_done = (int)std::min<long long>(done, INT32_MAX);
     c->info.last_eps = last;
     c->info.jacobi_launches = launches;
     prof.collect();
+    if (stalled)
+        return fail(c, HSFLOW_E_NOTERM, "EPS termination: Eps stopped decreasing above epsilon (fp32 limit cycle) -- "
+                                        "the flow of the sweeps done so far is kept");
     return HSFLOW_OK;
 }
 
@@ -513,6 +526,12 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     if (use_iter && p.max_iter <= 0 && !use_eps)
         return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
     if (!(p.lambda > 0.f) || !std::isfinite(p.lambda)) return fail(c, HSFLOW_E_ARG, "lambda must be positive");
+    // EPS with no sweep budget (EPS alone, or ITER|EPS with max_iter <= 0, which the original treats the same way,
+    // cv210.dll VA 0x1012f10b-0x1012f14a) stops only on Eps < epsilon: with epsilon <= 0 or NaN that never happens
+    // and the original spins forever.  Refused here; a positive epsilon below the fp32 limit cycle of the
+    // iteration is caught at run time (solve_eps_chunks).
+    if (use_eps && !(use_iter && p.max_iter > 0) && !(p.epsilon > 0.0 && std::isfinite(p.epsilon)))
+        return fail(c, HSFLOW_E_NOTERM, "EPS termination without a sweep budget needs a finite epsilon > 0");
     if (async && p.profile) return fail(c, HSFLOW_E_ARG, "solve_async does not support profiling");
 
     // Ilambda = fl32(1/fl32(lambda)), cv210.dll VA 0x1012e054-0x1012e085.  Kept out of the denormal range

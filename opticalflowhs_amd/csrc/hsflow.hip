@@ -391,6 +391,9 @@ int hsflow_get_flow_device(hsflow_ctx *c, int pair, int row0, int nrows, void *d
 {
     int st = flow_rows_args(c, pair, row0, nrows, du, us, dv, vs);
     if (st) return st;
+    // rows handed to another consumer on the device (halo exchange) must be final: an ITER|EPS check that
+    // hsflow_solve_async still owes is settled first (a re-run would change them)
+    if ((st = settle_pending(c))) return st;
     const size_t rowb = (size_t)c->W * 4;
     const long long off = pair * c->plane + (long long)row0 * c->P;
     HS_HIP(c, hipMemcpy2DAsync(du, us, c->dU[c->cur] + off, (size_t)c->P * 4, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));

@@ -262,6 +262,28 @@ def test_eps_termination_matches_oracle(hs, gpu_ok):
     assert info4["iterations_done"] == 40 and np.array_equal(u4, u5) and np.array_equal(v4, v5)
 
 
+def test_eps_only_gives_up_at_the_fp32_limit_cycle(hs, gpu_ok):
+    """EPS termination without a budget and an epsilon the fp32 iteration can never reach: the original would
+    spin forever; here the solve returns HSFLOW_E_NOTERM once Eps has stopped decreasing, with the flow kept."""
+    d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
+    with hs.HSFlow(48, 40, 1, own_stream=True) as ctx:
+        ctx.set_frames(d["A"], d["B"])
+        for kw in (dict(kernel=hs.KERNEL_AUTO), dict(kernel=hs.KERNEL_SIMPLE)):
+            with pytest.raises(hs.HsflowError) as e:
+                ctx.solve(lam=0.002, max_iter=0, epsilon=1e-30, term_type=EPS, **kw)
+            assert e.value.status == hs._lib.E_NOTERM
+            info = ctx.info()
+            assert 4096 <= info["iterations_done"] < (1 << 20) and 0 <= info["last_eps"] < 1e-5, info
+            u, v = ctx.flow()
+            assert np.isfinite(u).all() and np.isfinite(v).all() and np.abs(u).max() > 1e-3
+        # identical frames: Eps is exactly 0 after one sweep, any positive epsilon stops there; epsilon = 0 is refused
+        ctx.set_frames(d["A"], d["A"])
+        assert ctx.solve(lam=0.1, max_iter=0, epsilon=1e-30, term_type=EPS)["iterations_done"] == 1
+        with pytest.raises(hs.HsflowError) as e:
+            ctx.solve(lam=0.1, max_iter=0, epsilon=0.0, term_type=EPS)
+        assert e.value.status == hs._lib.E_NOTERM
+
+
 def test_use_previous_and_row_copies(hs, gpu_ok):
     import torch
     A, B = synth.random_pair(70, 33, seed=21)

@@ -109,6 +109,95 @@ def test_unsupported_and_broken_files_are_refused(jpeg2ppm, tmp_path):
     assert a is None and "not a JPEG" in err
 
 
+def _patch_sof(data, fn):
+    """Returns `data` with the SOF0 segment's payload rewritten by fn(bytearray payload)."""
+    b = bytearray(data)
+    i = 2
+    while i + 4 <= len(b):
+        assert b[i] == 0xFF
+        m, ln = b[i + 1], (b[i + 2] << 8) | b[i + 3]
+        if m == 0xC0:
+            seg = bytearray(b[i + 4:i + 2 + ln])
+            out = fn(seg)
+            return bytes(b[:i + 4]) + bytes(out) + bytes(b[i + 2 + ln:]) if out is not None else bytes(b)
+        if m == 0xDA:
+            break
+        i += 2 + ln
+    raise AssertionError("no SOF0")
+
+
+def test_malformed_headers_never_crash_under_sanitizers(tmp_path):
+    """Crafted headers: a zero sampling factor (division by zero), two SOF segments whose second one
+    lowers the sampling factors (planes smaller than the frame -> heap over-read in the colour conversion), an SOS
+    segment of length 2 (read past the segment), sampling factors of 3 / 4.  The decoder is built with
+    AddressSanitizer + UndefinedBehaviorSanitizer: every file must be refused (or decoded) without a report."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "jpeg2ppm_san")
+    src = os.path.join(ROOT, "opticalflowhs_amd", "csrc", "host", "jpeg2ppm.cpp")
+    r = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, src],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    arr = np.random.default_rng(2).integers(0, 256, size=(33, 47, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="JPEG", subsampling=2)   # 4:2:0: luma 2x2
+    good = buf.getvalue()
+    gbuf = io.BytesIO()
+    Image.fromarray(arr[:, :, 0]).save(gbuf, format="JPEG")
+    gray = gbuf.getvalue()
+
+    def sampling(seg, comp, hv):
+        seg[7 + 3 * comp] = hv
+        return seg
+
+    def sof_bytes(data):
+        i = data.index(b"\xff\xc0")
+        ln = (data[i + 2] << 8) | data[i + 3]
+        return i, data[i:i + 2 + ln]
+
+    cases = {}
+    cases["zero_h"] = _patch_sof(good, lambda s: sampling(s, 0, 0x02))
+    cases["zero_v"] = _patch_sof(good, lambda s: sampling(s, 0, 0x20))
+    cases["zero_chroma"] = _patch_sof(good, lambda s: sampling(s, 1, 0x00))
+    cases["h3"] = _patch_sof(good, lambda s: sampling(s, 0, 0x32))
+    cases["h4v4"] = _patch_sof(good, lambda s: sampling(s, 0, 0x44))
+    cases["gray_zero"] = _patch_sof(gray, lambda s: sampling(s, 0, 0x00))
+    # two frame headers: the first announces 4x4 luma sampling, the second the real 2x2 one
+    i, sof = sof_bytes(good)
+    first = bytearray(sof)
+    first[4 + 7] = 0x44
+    cases["double_sof"] = good[:i] + bytes(first) + good[i:]
+    cases["double_sof_same"] = good[:i] + sof + good[i:]
+    # SOS with length 2 (no payload), and one whose component count byte is the last byte of the file
+    j = good.index(b"\xff\xda")
+    cases["sos_len2"] = good[:j] + b"\xff\xda\x00\x02" + good[j + 4:]
+    cases["sos_len2_eof"] = good[:j] + b"\xff\xda\x00\x02"
+    cases["sos_len3_eof"] = good[:j] + b"\xff\xda\x00\x03\x03"
+    # frame larger than the entropy-coded data covers, 1x1 frame with the original scan
+    cases["huge_dims"] = _patch_sof(good, lambda s: s[:1] + bytes([0x10, 0x00, 0x10, 0x00]) + s[5:])
+    cases["tiny_dims"] = _patch_sof(good, lambda s: s[:1] + bytes([0x00, 0x01, 0x00, 0x01]) + s[5:])
+    cases["zero_dims"] = _patch_sof(good, lambda s: s[:1] + bytes([0x00, 0x00, 0x00, 0x00]) + s[5:])
+    rng = np.random.default_rng(7)
+    for k in range(40):   # random single-byte corruptions of the headers
+        b = bytearray(good)
+        pos = int(rng.integers(2, j + 14))
+        b[pos] = int(rng.integers(0, 256))
+        cases["fuzz%d" % k] = bytes(b)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".jpg"))
+        with open(p, "wb") as f:
+            f.write(data)
+        r = subprocess.run([exe, p, str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode in (0, 1), (name, r.returncode, r.stderr[-1500:])   # decoded or refused; 1 = refused with a message
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (name, r.stderr[-1500:])
+        if name in ("zero_h", "zero_v", "zero_chroma", "gray_zero", "double_sof", "double_sof_same", "sos_len2", "sos_len2_eof", "sos_len3_eof", "zero_dims"):
+            assert r.returncode == 1, (name, r.stderr)
+
+
 def test_reference_inputs_give_the_committed_gray_planes(jpeg2ppm, oracle, tmp_path):
     """The reference's own input pictures through the CLI's reader and BGR2GRAY = the gray planes every
     other test works on (those were made with PIL's decoder)."""

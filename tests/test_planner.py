@@ -86,3 +86,17 @@ def test_planner_known_configs_and_refusals(hs):
     with pytest.raises(hs.HsflowError) as e:
         hs.plan_query(64, 64, max_iter=5, kernel=99)
     assert e.value.status == hs._lib.E_ARG
+
+
+def test_eps_without_budget_needs_a_usable_epsilon(hs):
+    """EPS alone (or ITER|EPS with max_iter <= 0) stops only on Eps < epsilon: epsilon <= 0, NaN or inf would never
+    stop (the original spins forever, cv210.dll VA 0x1012f10b-0x1012f14a) -> HSFLOW_E_NOTERM."""
+    for tt, it in ((hs.TERM_EPS, 0), (hs.TERM_EPS, 50), (hs.TERM_ITER | hs.TERM_EPS, 0), (hs.TERM_ITER | hs.TERM_EPS, -3)):
+        for eps in (0.0, -1e-6, float("nan"), float("inf")):
+            with pytest.raises(hs.HsflowError) as e:
+                hs.plan_query(64, 64, max_iter=it, term_type=tt, epsilon=eps)
+            assert e.value.status == hs._lib.E_NOTERM, (tt, it, eps)
+        assert hs.plan_query(64, 64, max_iter=it, term_type=tt, epsilon=1e-6)["kernel"] in (hs.KERNEL_FOLD, hs.KERNEL_STRIP)
+    # with a sweep budget any epsilon is fine: ITER ends the solve
+    for eps in (0.0, -1.0, float("nan")):
+        assert hs.plan_query(64, 64, max_iter=7, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=eps)["jacobi_launches"] >= 1
