@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Horn-Schunck hot path on MI355X: Mpixel*iterations/sec.
 
-One "step" = one pass of the hot path (derivative kernel + `iters` Jacobi sweeps) over one batch
-of `pairs` synthetic image pairs per GPU, frames already resident in HBM, result left in HBM.
-Default workload = BASELINE.json configs[1]: one 1920x1080 translating-texture pair (seed 1),
-lambda 1, 100 iterations, fp32, 1 GPU.  With --gpus N every rank runs the same per-GPU batch on its
-own pairs (independent pairs shard with no collective: "scaling": "weak"); the only communication
-is the barrier + max-over-ranks of the elapsed time.
+One "step" = one pass of the hot path (derivative pass + `iters` Jacobi sweeps) over one batch of `pairs`
+synthetic image pairs per GPU, frames already resident in HBM, result left in HBM.  Default workload =
+BASELINE.json configs[1]: one 1920x1080 translating-texture pair (seed 1), lambda 1, 100 iterations, fp32,
+1 GPU.  The solver is called the way the reference calls it -- ITER|EPS with eps 1e-6
+(OpticalFlowOpenCV.cpp:29) -- through hsflow_solve_async; the ITER-only form is timed beside it.
+With --gpus N every rank runs the same per-GPU batch on its own pairs (independent pairs shard with no
+collective: "scaling": "weak"); the only communication of the headline is the barrier + max-over-ranks of
+the elapsed time.  For N > 1 two more measurements ride in the same JSON line (extra keys): `c4_pipeline`
+(BASELINE config C4: 512 host-resident pairs over the ranks through the pair pipeline, PCIe included) and
+`c5_slab` (config C5: one 16384^2 frame in row slabs, halo rows exchanged with RCCL send/recv).
 
 Launch: python bench.py [--gpus 1]   or, for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,6 +32,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 ALG_BYTES_PER_PX_ITER = 28.0    # read Ix,Iy,It,u,v + write u',v' as fp32 planes
+ALG_FLOPS_PER_PX_ITER = 22.0    # SURVEY.md 8d (informational flop count of one update)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+# VALU-issue roofline (the bound that binds the multi-sweep kernels):
+N_SIMD = 256 * 4                # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
+SPEC_CLOCK_GHZ = 2.4            # chip table, max clock
+SPEC_CYCLES_PER_WAVE64_OP = 2.0  # SIMD-32: a wave64 VALU instruction issues over 2 cycles
+MEASURED_CYCLES_PER_WAVE64_OP = 2.3   # profiles/r01_ubench_valu.txt: v_add/fma/mov_f32 at 2-4 wavefronts per SIMD
+MEASURED_CLOCK_GHZ = 2.14             # profiles/r01_phase_stamps_1080p.txt: s_memtime / s_memrealtime under this kernel
 
 
 def parse():
@@ -33,24 +47,138 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps (the first one is `value`; the rest give the spread)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--pairs", type=int, default=1, help="pairs per GPU per step")
     ap.add_argument("--lam", type=float, default=1.0)
-    ap.add_argument("--kernel", choices=["auto", "simple", "fused", "strip"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "simple", "fused", "strip", "fold"], default="auto")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--fuse-steps", type=int, default=0)
     ap.add_argument("--tile-w", type=int, default=0)
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--iter-eps", action="store_true",
-                    help="time the reference's own call form ITER|EPS (eps 1e-6) instead of ITER only (synchronous solves)")
+    ap.add_argument("--iter-only", action="store_true", help="headline with ITER termination instead of the reference's ITER|EPS")
+    ap.add_argument("--sync-solves", action="store_true", help="hsflow_solve (host waits for every solve) instead of hsflow_solve_async")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the single-thread cpu_baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0: same as --iters)")
+    # multi-GPU extras (default: on for N > 1, off for N = 1)
+    ap.add_argument("--c4", choices=["auto", "on", "off"], default="auto", help="config C4: host-resident pairs through the pair pipeline")
+    ap.add_argument("--c4-pairs", type=int, default=512, help="pairs of config C4 over all ranks")
+    ap.add_argument("--c4-pool", type=int, default=8, help="distinct synthetic pairs per rank that the C4 submissions cycle through")
+    ap.add_argument("--c5", choices=["auto", "on", "off"], default="auto", help="config C5: one frame in row slabs with halo exchange")
+    ap.add_argument("--c5-size", type=int, default=16384)
+    ap.add_argument("--c5-iters", type=int, default=500)
+    ap.add_argument("--c5-halo", type=int, default=16)
+    ap.add_argument("--c5-check", choices=["on", "off"], default="on", help="owned rows against a rank-local band solve, bit for bit")
     return ap.parse_args()
+
+
+def gen_rows(synth, W, H, seed, row0, rows, block=512):
+    """Rows [row0, row0+rows) of the translating-texture pair, generated in blocks (bounded host memory)."""
+    A = np.empty((rows, W), np.uint8)
+    B = np.empty((rows, W), np.uint8)
+    for r in range(0, rows, block):
+        n = min(block, rows - r)
+        A[r:r + n], B[r:r + n] = synth.translating_pair(W, H, seed=seed, row0=row0 + r, rows=n)
+    return A, B
+
+
+def run_c4(args, hs, synth, dist, world, rank, local_rank, barrier, reduce_max):
+    """BASELINE config C4 with the PCIe legs: --c4-pairs host-resident 1080p pairs sharded over the ranks
+    (pair i -> rank i mod world, slab.shard_pairs), each rank streaming its share through the pair pipeline at
+    depth 4 (page-locked buffers; upload, solve and download of neighbouring pairs overlap).  The submissions
+    cycle through a pool of distinct synthetic pairs (seeds 1000 + global pair index); timing does not depend
+    on the pixel values."""
+    from opticalflowhs_amd import slab
+    W, H, it = 1920, 1080, 100
+    mine = slab.shard_pairs(args.c4_pairs, world, rank)
+    pool = max(1, min(args.c4_pool, len(mine)))
+    ins = []
+    for k in range(pool):
+        A, B = synth.translating_pair(W, H, seed=1000 + mine[k])
+        a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)
+        a[...], b[...] = A, B
+        ins.append((a, b))
+    depth = 4
+    outs = [(hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)) for _ in range(depth + 1)]
+    eps6 = float(np.float32(1e-6))
+    p = hs.make_params(lam=1.0, max_iter=it, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=eps6, use_graph=True)
+    with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
+        for k in range(min(2 * depth, len(mine))):  # warm-up: plans, graphs, first-touch of the buffers
+            pl.submit(ins[k % pool][0], ins[k % pool][1], outs[k % (depth + 1)][0], outs[k % (depth + 1)][1], params=p)
+        pl.drain()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(len(mine)):
+            pl.submit(ins[k % pool][0], ins[k % pool][1], outs[k % (depth + 1)][0], outs[k % (depth + 1)][1], params=p)
+        pl.drain()
+        barrier()
+        el = reduce_max(time.perf_counter() - t0)
+    return {"config": "C4: %d host-resident 1920x1080 pairs, 100 iterations (ITER|EPS, eps 1e-6), pair pipeline depth %d, PCIe inclusive"
+                      % (args.c4_pairs, depth),
+            "pairs_total": args.c4_pairs, "pairs_this_rank": len(mine), "distinct_pairs_per_rank": pool, "seconds": el,
+            "pairs_per_s": args.c4_pairs / el, "value": args.c4_pairs * W * H * it / el / 1e6, "unit": "Mpix*iter/s",
+            "collective": "none (barrier for timing only)"}
+
+
+def run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max):
+    """BASELINE config C5: one --c5-size^2 frame (seed 3) in row slabs over the ranks, --c5-iters sweeps in
+    chunks of --c5-halo with `halo` rows of u, v swapped between neighbouring ranks after every chunk
+    (torch.distributed batch_isend_irecv = RCCL send/recv on the GPU box).  Both drivers are timed: the plain
+    one and the overlapped one (two sub-slabs per rank).  Check: each rank re-solves a band = its owned rows
+    plus `iters` rows of margin either side in an ordinary one-context solve (exact for the owned rows, a
+    border error travels one row per sweep) and compares bit for bit."""
+    from opticalflowhs_amd import slab
+    S, it, halo = args.c5_size, args.c5_iters, args.c5_halo
+    out = {"config": "C5: one %dx%d frame (seed 3), %d iterations, row slabs over %d rank(s), halo %d rows exchanged every %d sweeps"
+                     % (S, S, it, world, halo, halo),
+           "backend": backend, "unit": "Mpix*iter/s", "bytes_per_exchange_per_boundary": 2 * 2 * halo * S * 4}
+    stage = backend != "nccl"
+    for name in ("plain", "overlap"):
+        if name == "overlap":
+            s = slab.OverlappedSlabSolver(dist, rank, world, S, S, halo,
+                                          lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local_rank, torch_stream=torch.cuda.Stream(device=local_rank)),
+                                          stage_on_host=stage)
+        else:
+            ts = torch.cuda.current_stream(local_rank)
+            s = slab.SlabSolver(dist, rank, world, S, S, halo,
+                                lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local_rank, stream=ts.cuda_stream), stage_on_host=stage)
+        r0, r1 = s.local_frame_rows()
+        A, B = gen_rows(synth, S, S, 3, r0, r1 - r0)
+        s.set_frames(A, B)
+        s.solve(1.0, min(it, 2 * halo))  # warm-up: plans, graphs, communicators
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        n_ex = s.solve(1.0, it)
+        torch.cuda.synchronize()
+        barrier()
+        el = reduce_max(time.perf_counter() - t0)
+        out[name] = {"seconds": el, "value": S * S * it / el / 1e6, "exchanges": n_ex}
+        if args.c5_check == "on" and name == "plain":
+            lo, hi = s.lo, s.hi
+            b0, b1 = max(0, lo - it), min(S, hi + it)
+            Ab, Bb = (A, B) if (b0, b1) == (r0, r1) else gen_rows(synth, S, S, 3, b0, b1 - b0)
+            with hs.HSFlow(S, b1 - b0, 1, device=local_rank, own_stream=True) as band:
+                band.set_frames(Ab, Bb)
+                band.solve(lam=1.0, max_iter=it, term_type=hs.TERM_ITER)
+                ub, vb = band.flow()
+            uo, vo = s.owned_flow()
+            ok = bool(np.array_equal(uo, ub[lo - b0:hi - b0]) and np.array_equal(vo, vb[lo - b0:hi - b0]))
+            del ub, vb, uo, vo, Ab, Bb
+            if world > 1:
+                t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = bool(t.item() == 1.0)
+            out["owned_rows_bit_identical_to_band_solve"] = ok
+        s.close()
+        del A, B
+    out["value"] = max(out["plain"]["value"], out["overlap"]["value"])
+    return out
 
 
 def main():
@@ -88,7 +216,8 @@ def main():
     from opticalflowhs_amd import synth
 
     W, H, iters, pairs = args.width, args.height, args.iters, args.pairs
-    kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP}[args.kernel]
+    kernel = {"auto": hs.KERNEL_AUTO, "simple": hs.KERNEL_SIMPLE, "fused": hs.KERNEL_FUSED, "strip": hs.KERNEL_STRIP,
+              "fold": hs.KERNEL_FOLD}[args.kernel]
     # all work goes to one non-default stream (the legacy default stream cannot be graph-captured)
     tstream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(tstream)
@@ -103,46 +232,60 @@ def main():
             frames = [A, B]
         ctx.set_frames(A, B, pair=i)
 
-    p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
-                        fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
-                        threads=args.threads, strip_rows=args.strip_rows, use_graph=not args.no_graph)
+    eps6 = float(np.float32(1e-6))
+    tune = dict(lam=args.lam, max_iter=iters, kernel=kernel, fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
+                threads=args.threads, strip_rows=args.strip_rows)
+    p_iter = ctx.make_params(term_type=hs.TERM_ITER, use_graph=not args.no_graph, **tune)
+    p_ieps = ctx.make_params(term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=eps6, use_graph=not args.no_graph, **tune)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    if args.iter_eps:  # the early-stop check needs one read-back per solve: synchronous solves
-        p = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER | hs.TERM_EPS,
-                            epsilon=float(np.float32(1e-6)), kernel=kernel, fuse_steps=args.fuse_steps,
-                            tile_w=args.tile_w, tile_h=args.tile_h, threads=args.threads, strip_rows=args.strip_rows,
-                            use_graph=not args.no_graph)
-        step = lambda: ctx.solve(p)
-    else:
-        step = lambda: ctx.solve_async(p)
+    def reduce_max(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def stepper(p):
+        return (lambda: ctx.solve(p)) if args.sync_solves else (lambda: ctx.solve_async(p))
+
+    def timed_block(step):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        return reduce_max(time.perf_counter() - t0)
+
+    head_p, side_p = (p_iter, p_ieps) if args.iter_only else (p_ieps, p_iter)
+    head_name, side_name = ("ITER", "ITER|EPS (eps 1e-6)") if args.iter_only else ("ITER|EPS (eps 1e-6)", "ITER")
+    step = stepper(head_p)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    info = ctx.info()
+    # THE timed region of the contract: exactly --steps steps between barrier + synchronize, max over ranks
+    elapsed = timed_block(step)
+    info = ctx.info()   # (settles the last solve's early-stop check: iterations_done / eps_rerun are final)
+    # spread: the same block again, --blocks - 1 more times
+    block_ms = [elapsed / args.steps * 1e3] + [timed_block(step) / args.steps * 1e3 for _ in range(max(0, args.blocks - 1))]
+    # the other termination form beside it (same steps, same block structure)
+    step2 = stepper(side_p)
+    for _ in range(min(args.warmup, 5)):
+        step2()
+    side_ms = [timed_block(step2) / args.steps * 1e3 for _ in range(max(1, min(args.blocks, 3)))]
+    info2 = ctx.info()
 
-    # Per-kernel durations with HIP events on the launch stream: same K steps again, eager launches
-    # bracketed by hipEventRecord inside the C ABI (params.profile).  Events between launches would
-    # perturb the timed region above, so they run right after it, same process, same buffers.
-    pp = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER, kernel=kernel,
-                         fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h,
-                         threads=args.threads, strip_rows=args.strip_rows, profile=True)
+    # Per-kernel durations with HIP events on the launch stream: eager launches of the same solve bracketed by
+    # hipEventRecord inside the C ABI (params.profile).  Events between graph nodes would perturb the timed
+    # region above, so they run right after it, same process, same buffers.  (The derivative pass is a kernel
+    # of its own here; in the timed region it rides in the first Jacobi launch.)
+    pp = ctx.make_params(term_type=hs.TERM_ITER, profile=True, **tune)
     jac_ms = der_ms = 0.0
     launches = 0
     nprof = max(1, min(args.steps, 50))
@@ -152,73 +295,107 @@ def main():
         der_ms += pi["deriv_ms"]
         launches += pi["jacobi_launches"]
 
-    # the same workload with the termination criteria the reference itself passes (ITER|EPS, eps 1e-6,
-    # OpticalFlowOpenCV.cpp:29): synchronous solves, reported beside the headline, not instead of it
-    eps_line = None
-    if not args.iter_eps and world == 1:
-        pe = ctx.make_params(lam=args.lam, max_iter=iters, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=float(np.float32(1e-6)),
-                             kernel=kernel, fuse_steps=args.fuse_steps, tile_w=args.tile_w, tile_h=args.tile_h, threads=args.threads,
-                             strip_rows=args.strip_rows, use_graph=not args.no_graph)
-        for _ in range(3):
-            ctx.solve(pe)
-        ne = max(5, min(args.steps, 30))
-        te = time.perf_counter()
-        for _ in range(ne):
-            ie = ctx.solve(pe)
-        te = (time.perf_counter() - te) / ne
-        eps_line = {"criteria": "ITER|EPS, eps 1e-6 (synchronous solves)", "ms_per_step": te * 1e3,
-                    "value": W * H * pairs * iters / te / 1e6, "iterations_done": ie["iterations_done"], "eps_rerun": ie["eps_rerun"]}
-
     KNAME = {hs.KERNEL_SIMPLE: "simple", hs.KERNEL_FUSED: "fused", hs.KERNEL_STRIP: "strip", hs.KERNEL_FOLD: "fold"}
     px = W * H * pairs
     ms_per_step = elapsed / args.steps * 1e3
     value = world * px * iters * args.steps / elapsed / 1e6
     avg_launch_ms = jac_ms / max(launches, 1)
     sweeps_per_launch = iters * nprof / max(launches, 1)
+    jac_us_per_step = jac_ms / nprof * 1e3
+
+    # --- roofline of the dominant kernel (the Jacobi launch) ------------------------------------------------
+    # VALU issue is what binds the multi-sweep kernels: several sweeps run per launch out of registers, so the
+    # 28 B/pixel/sweep of SURVEY.md 8d are not what HBM moves (kept below as hbm_algorithmic; it exceeds the HBM
+    # peak and is no bound).  op slots = wave64 VALU lane-operations the update needs per pixel and sweep as the
+    # kernels compute it (hsflow_info... see OP_SLOTS below); peak = all SIMDs issuing one such operation per
+    # MEASURED_CYCLES_PER_WAVE64_OP cycles at the clock the chip holds under this kernel.
+    op_slots = hs.OP_SLOTS_PER_PIXEL_SWEEP
+    lane_ops_per_launch = op_slots * px * sweeps_per_launch
+    peak_measured = N_SIMD * 64.0 / MEASURED_CYCLES_PER_WAVE64_OP * MEASURED_CLOCK_GHZ * 1e9 / 1e12   # Tlane-op/s
+    peak_spec = N_SIMD * 64.0 / SPEC_CYCLES_PER_WAVE64_OP * SPEC_CLOCK_GHZ * 1e9 / 1e12
+    achieved_valu = lane_ops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    ideal_us_per_step = op_slots * px * iters / (peak_measured * 1e12) * 1e6
     alg_bytes_per_launch = ALG_BYTES_PER_PX_ITER * px * sweeps_per_launch
-    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    alg_gbps = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    multi = info["kernel"] != hs.KERNEL_SIMPLE
+    roof = {
+        "bound": "valu" if multi else "hbm",
+        "kernel": "k_jacobi_" + KNAME[info["kernel"]],
+        "avg_launch_us": avg_launch_ms * 1e3, "sweeps_per_launch": sweeps_per_launch,
+        "traffic": None, "traffic_measured_in_run": False,
+        "valu_issue": {
+            "op_slots_per_pixel_sweep": op_slots, "lane_ops_per_launch": lane_ops_per_launch,
+            "achieved_Tlaneops": achieved_valu,
+            "peak_Tlaneops_measured_issue": peak_measured, "peak_Tlaneops_spec": peak_spec,
+            "frac_of_measured_issue": achieved_valu / peak_measured, "frac_of_spec": achieved_valu / peak_spec,
+            "ideal_us_per_step": ideal_us_per_step, "jacobi_kernel_us_per_step": jac_us_per_step,
+            "constants": {"simds": N_SIMD, "cycles_per_wave64_op_measured": MEASURED_CYCLES_PER_WAVE64_OP,
+                          "clock_ghz_measured": MEASURED_CLOCK_GHZ, "cycles_per_wave64_op_spec": SPEC_CYCLES_PER_WAVE64_OP,
+                          "clock_ghz_spec": SPEC_CLOCK_GHZ,
+                          "source": "profiles/r01_ubench_valu.txt (issue cost), profiles/r01_phase_stamps_1080p.txt (clock), "
+                                    "MI355X_MICROARCH.md (SIMD-32, 256 CUs x 4 SIMDs, 2.4 GHz)"},
+            "note": "ideal_us_per_step = op_slots x pixels x sweeps / measured-issue peak; frac = ideal / measured Jacobi kernel time"},
+        "fp32_vector": {"flops_per_pixel_sweep": ALG_FLOPS_PER_PX_ITER,
+                        "achieved_TFLOPs": ALG_FLOPS_PER_PX_ITER * px * sweeps_per_launch / (avg_launch_ms * 1e-3) / 1e12,
+                        "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS},
+        "hbm_algorithmic": {"bytes_per_pixel_sweep": ALG_BYTES_PER_PX_ITER, "bytes_per_launch": alg_bytes_per_launch, "GBps": alg_gbps,
+                            "ratio_to_hbm_peak": alg_gbps / HBM_PEAK_GBS,
+                            "note": "SURVEY.md 8d accounting (28 B/pixel/sweep x pixels x sweeps per launch / launch time); with several "
+                                    "sweeps per launch this is not what HBM moves and may exceed the peak -- not a bound"},
+    }
+    roof["fp32_vector"]["frac"] = roof["fp32_vector"]["achieved_TFLOPs"] / FP32_VECTOR_PEAK_TFLOPS
+    if multi:
+        roof.update({"achieved": achieved_valu, "peak": peak_measured, "unit": "Tlane-op/s", "frac": achieved_valu / peak_measured})
+    else:
+        roof.update({"achieved": alg_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbps / HBM_PEAK_GBS})
+
+    # HBM bytes per launch from a committed PMC summary (tools/collect_profiles.py) taken on this very launch shape:
+    # kernel, sweeps per launch, rows per lane, workgroup size, frame size.  Not measured in this run (PMC needs
+    # rocprofv3); null when no summary matches.
+    for traffic_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            tr = json.load(open(traffic_file))
+        except (ValueError, OSError):
+            continue
+        want = {"kernel": roof["kernel"], "width": W, "height": H, "pairs": pairs, "fuse_steps": info["fuse_steps"],
+                "rows_per_lane_or_groups": info["groups_per_thread"], "threads": info["threads"]}
+        if all(tr.get(k) == v for k, v in want.items()) and tr.get("hbm_bytes_per_launch"):
+            roof["traffic"] = tr["hbm_bytes_per_launch"]
+            roof["hbm_traffic"] = {"bytes_per_launch": tr["hbm_bytes_per_launch"], "measured_in_run": False,
+                                   "source": tr.get("source"), "file": os.path.relpath(traffic_file, ROOT), "tag": tr.get("tag"),
+                                   "GBps": tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9,
+                                   "frac_of_hbm_peak": tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            break
 
     out = {
         "metric": "Mpixel*iterations/sec (Horn-Schunck: derivative pass + Jacobi u/v sweeps, frames resident in HBM)",
         "value": value, "unit": "Mpix*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, ITER termination"
-                               % (W, H, pairs, args.lam, iters),
+        "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, %s termination"
+                               % (W, H, pairs, args.lam, iters, head_name),
                    "width": W, "height": H, "iters": iters, "pairs_per_gpu": pairs, "lambda": args.lam,
                    "kernel": KNAME[info["kernel"]],
                    "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
-                   "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"], "lds_bytes": info["lds_bytes"],
-                   "hipgraph": not args.no_graph,
-                   "termination": "ITER|EPS (eps 1e-6)" if args.iter_eps else "ITER", "sharding": "independent pairs per rank, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_jacobi_" + KNAME[info["kernel"]],
-                     "avg_launch_us": avg_launch_ms * 1e3, "sweeps_per_launch": sweeps_per_launch,
-                     "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "note": "achieved = 28 B/pixel/sweep x pixels x sweeps per launch / mean launch time (HIP events); "
-                             "the kernel runs several sweeps per launch out of registers / LDS, so this can exceed what HBM moves"},
+                   "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"],
+                   "lds_bytes": info["lds_bytes"], "hipgraph": not args.no_graph, "termination": head_name,
+                   "call": "hsflow_solve" if args.sync_solves else "hsflow_solve_async",
+                   "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"],
+                   "sharding": "independent pairs per rank, no collective"},
+        "ms_per_step_blocks": block_ms, "ms_per_step_min": min(block_ms), "ms_per_step_median": statistics.median(block_ms),
+        "ms_per_step_max": max(block_ms),
+        "roofline": roof,
         "kernel_ms_per_step": {"deriv": der_ms / nprof, "jacobi": jac_ms / nprof, "launches": launches / nprof},
+        "other_termination": {"termination": side_name, "ms_per_step": statistics.median(side_ms), "ms_per_step_blocks": side_ms,
+                              "value": world * px * iters / (statistics.median(side_ms) * 1e-3) / 1e6,
+                              "iterations_done": info2["iterations_done"], "eps_rerun": info2["eps_rerun"]},
     }
-    if eps_line:
-        out["reference_call_criteria"] = eps_line
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size()
+        out["backend"] = backend
 
-    # HBM bytes per launch from the committed PMC summaries (tools/collect_profiles.py): whichever one was
-    # taken on this workload with this launch depth
-    import glob
-    for traffic_file in [os.path.join(ROOT, "profiles", "traffic_latest.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
-        try:
-            tr = json.load(open(traffic_file))
-        except (ValueError, OSError):
-            continue
-        if tr.get("width") == W and tr.get("height") == H and tr.get("fuse_steps") == info["fuse_steps"] and tr.get("hbm_bytes_per_launch"):
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr.get("source")
-            out["roofline"]["traffic_GBps"] = tr["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9  # what HBM physically moves
-            break
-
-    # the roofline fraction also against what a plain device-to-device copy reaches on this box
-    # (1 GiB read + 1 GiB written per copy, torch's copy kernel, HIP events on torch's stream)
+    # what a plain device-to-device copy reaches on this box (1 GiB read + 1 GiB written per copy,
+    # torch's copy kernel, HIP events on torch's stream) -- context for the hbm figures
     if rank == 0:
         try:
             n = 1 << 28  # floats
@@ -234,12 +411,19 @@ def main():
                 dst.copy_(src)
             e1.record()
             torch.cuda.synchronize()
-            copy_gbps = 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            out["roofline"]["measured_copy_GBps"] = copy_gbps
-            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbps
+            roof["measured_copy_GBps"] = 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del src, dst
         except RuntimeError:
             pass
+    ctx.close()
+
+    # --- multi-GPU configs of BASELINE.json beside the headline ---------------------------------------------
+    want_c4 = args.c4 == "on" or (args.c4 == "auto" and world > 1)
+    want_c5 = args.c5 == "on" or (args.c5 == "auto" and world > 1)
+    if want_c4:
+        out["c4_pipeline"] = run_c4(args, hs, synth, dist, world, rank, local_rank, barrier, reduce_max)
+    if want_c5:
+        out["c5_slab"] = run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max)
 
     if rank == 0 and world == 1 and not args.skip_cpu:
         from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
@@ -266,7 +450,6 @@ def main():
         n2, t2 = timed(0, 0.3 * args.cpu_seconds)
         out["cpu_baseline_all_cores"] = {"value": W * H * cit * n2 / t2 / 1e6, "unit": "Mpix*iter/s", "cores": nth, "kind": "port",
                                          "sample": "%d solves of the same pair, OpenMP row-parallel form, %.1f s" % (n2, t2)}
-    ctx.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define HSFLOW_VERSION_MAJOR 0
-#define HSFLOW_VERSION_MINOR 3 /* 0.3: hsflow_info.deriv_fused */
+#define HSFLOW_VERSION_MINOR 4 /* 0.4: repeated asynchronous ITER|EPS solves pass the owed check on; E_NOTERM for EPS-only stalls */
 
 /* status codes (0 = success, like SDK_SUCCESS) */
 #define HSFLOW_OK 0
@@ -106,7 +106,10 @@ typedef struct hsflow_info {
     uint32_t struct_size;
     int32_t width, height, n_pairs, pitch; /* pitch in elements, same for every plane    */
     int32_t iterations_done;  /* sweeps executed by the last solve                        */
-    float last_eps;           /* Eps of the last sweep (EPS termination only)             */
+    float last_eps;           /* Eps of the last sweep (EPS termination only).  An asynchronous
+                                 ITER|EPS solve does not measure it; hsflow_get_info then runs that
+                                 solve's last launch once more to obtain it (NaN if the flow was
+                                 changed through hsflow_set_flow_device in between)               */
     int32_t kernel;           /* kernel actually used                                     */
     int32_t fuse_steps, tile_w, tile_h, threads, groups_per_thread;
     int32_t tiles;            /* workgroups per fused launch                              */
@@ -173,7 +176,10 @@ int hsflow_push_frame_u8(hsflow_ctx *ctx, int pair, const uint8_t *next, size_t 
  * fold kernels (what AUTO picks): the early-stop check is then owed until hsflow_synchronize / hsflow_get_flow /
  * hsflow_get_info / the next solve settles it -- if the fast pass cannot prove that the stop
  * never fired, the solve is repeated exactly (hsflow_info.eps_rerun = 1), so flow copied out by
- * an earlier hsflow_get_flow_async has to be fetched again in that case. */
+ * an earlier hsflow_get_flow_async has to be fetched again in that case.  One exception keeps a
+ * stream of solves free of host round trips: an hsflow_solve_async that repeats the owed solve bit
+ * for bit (same parameters, use_previous = 0; the frames cannot have changed, setting them settles)
+ * recomputes the same result and takes the owed check over instead of waiting for it. */
 int hsflow_solve(hsflow_ctx *ctx, const hsflow_params *params);
 int hsflow_solve_async(hsflow_ctx *ctx, const hsflow_params *params);
 int hsflow_synchronize(hsflow_ctx *ctx);
@@ -203,6 +209,9 @@ int hsflow_get_frames_u8(hsflow_ctx *ctx, int pair, uint8_t *prev, size_t prev_s
 /* --- introspection ------------------------------------------------------------------------ */
 
 int hsflow_get_info(hsflow_ctx *ctx, hsflow_info *info);
+/* measure_last_eps = 0: as hsflow_get_info, but last_eps of an asynchronous ITER|EPS solve is left as it is
+ * (NaN until measured) instead of running that solve's last launch again; 1: hsflow_get_info. */
+int hsflow_get_info_ex(hsflow_ctx *ctx, hsflow_info *info, int measure_last_eps);
 const char *hsflow_last_error(hsflow_ctx *ctx); /* ctx may be NULL: last create() error */
 const char *hsflow_status_string(int status);
 int hsflow_version(void); /* major*1000 + minor */

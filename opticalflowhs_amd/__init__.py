@@ -12,6 +12,11 @@ from .pipeline import PairPipeline, pinned_empty
 
 __all__ = ["HSFlow", "PairPipeline", "pinned_empty", "make_params", "plan_query", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
            "TERM_ITER", "TERM_EPS", "MODE_CV", "MODE_CLASSIC", "MODE_CLASSIC_AS_SHIPPED", "KERNEL_AUTO", "KERNEL_SIMPLE",
-           "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD"]
+           "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD", "OP_SLOTS_PER_PIXEL_SWEEP"]
+
+# Wave64 VALU lane-operations one pixel costs per Jacobi sweep in the multi-sweep kernels' arithmetic (csrc/hs_kernels_strip.hip.h,
+# strip_row_update): 3 + 3 additions for the two neighbour sums, 4 fused multiply-adds for the update, 1 multiplication that
+# carries the constant term to the next sweep's scale.  bench.py prices the VALU-issue roofline with it.
+OP_SLOTS_PER_PIXEL_SWEEP = 11
 
 _lib.load()  # fail loudly at import time if the HIP library is absent

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "hsflow_get_derivatives": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
     "hsflow_get_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_info": (_i, [_vp, ctypes.POINTER(HsflowInfo)]),
+    "hsflow_get_info_ex": (_i, [_vp, ctypes.POINTER(HsflowInfo), _i]),
     "hsflow_last_error": (ctypes.c_char_p, [_vp]),
     "hsflow_status_string": (ctypes.c_char_p, [_i]),
     "hsflow_version": (_i, []),

@@ -61,6 +61,48 @@ struct StripGeom {
     int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
 };
 
+// The last launch of a witness pass also reduces the per-workgroup words of ALL the pass's launches to one word
+// per row, straight into the host's page-locked buffer -- no reduction kernel, no kernel boundary behind the solve.
+// "Last workgroup reduces": every workgroup publishes its word(s) with write-through (sc1) stores, drains them,
+// then takes a ticket from an agent-scope counter; the workgroup whose ticket is the last one reads every row
+// with sc1 loads (the words of earlier launches are visible across the kernel boundary, those of this launch
+// through the drained write-through stores and the ticket: MI355X_MICROARCH.md, inter-workgroup visibility,
+// "one lane of each storing workgroup ... the workgroup whose add came last").  counter == nullptr: not wanted.
+struct EpsFinish {
+    unsigned *counter;        // zero between launches; the last workgroup resets it
+    const unsigned *rows;     // [n_rows][stride] words
+    unsigned *host_out;       // device address of page-locked host memory: n_rows words
+    int n_rows, stride;
+    int n_first, cnt_first, cnt_last; // rows [0, n_first) hold cnt_first valid words, the others cnt_last
+};
+
+// called by wavefront 0 of every workgroup after lane 0 has stored this workgroup's words (write-through)
+__device__ __forceinline__ void eps_finish(const EpsFinish &f, int lane)
+{
+    unsigned ticket = 0;
+    if (lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the words have left this CU before the ticket is drawn
+        ticket = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket != gridDim.x - 1) return;
+    for (int row = 0; row < f.n_rows; row++) {
+        const int n = row < f.n_first ? f.cnt_first : f.cnt_last;
+        const unsigned *src = f.rows + (size_t)row * f.stride;
+        unsigned m = 0;
+        for (int i = lane; i < n; i += 64) {
+            const unsigned x = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = x > m ? x : m; // bit patterns of non-negative floats order like unsigned integers
+        }
+        const float y = wave_max_nonneg(__uint_as_float(m));
+        if (lane == 0) f.host_out[row] = __float_as_uint(y);
+    }
+    if (lane == 0) {
+        __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+    }
+}
+
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
 __device__ __forceinline__ int mirror_index(int i, int n)
 {
@@ -231,7 +273,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
                                                         const float eps_thr, const uint8_t *__restrict__ fA,
-                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
+                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w,
+                                                        const EpsFinish fin)
 {
     // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
     // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
@@ -553,11 +596,12 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
+            if (lane == 0) __hip_atomic_store(eps_out + blockIdx.x, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
-                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
+                if (lane == 0) __hip_atomic_store(eps_out + (size_t)eps_stride + blockIdx.x, __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (fin.counter) eps_finish(fin, lane);
         }
     }
 #undef HS_ROW
@@ -606,10 +650,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         const float ilambda,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
-                                                        const float eps_thr)
+                                                        const float eps_thr, const EpsFinish fin)
 {
     strip_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                     nullptr, nullptr, nullptr);
+                                     nullptr, nullptr, nullptr, fin);
 }
 
 // First launch of a solve with the derivative pass folded in: reads the two frames instead of the packed
@@ -625,10 +669,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__r
                                                               const float ilambda,
                                                               unsigned *__restrict__ eps_out, const int eps_stride,
                                                               unsigned long long *__restrict__ stamps,
-                                                              const float eps_thr)
+                                                              const float eps_thr, const EpsFinish fin)
 {
     strip_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                    fA, fB, coef_w);
+                                    fA, fB, coef_w, fin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -663,7 +707,8 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps,
                                                        const float eps_thr, const uint8_t *__restrict__ fA,
-                                                       const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
+                                                       const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w,
+                                                       const EpsFinish fin)
 {
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -885,11 +930,12 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
+            if (lane == 0) __hip_atomic_store(eps_out + blockIdx.x, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
-                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
+                if (lane == 0) __hip_atomic_store(eps_out + (size_t)eps_stride + blockIdx.x, __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (fin.counter) eps_finish(fin, lane);
         }
     }
 #undef HF_ROW
@@ -928,10 +974,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        const float ilambda,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps,
-                                                       const float eps_thr)
+                                                       const float eps_thr, const EpsFinish fin)
 {
     fold_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                    nullptr, nullptr, nullptr);
+                                    nullptr, nullptr, nullptr, fin);
 }
 
 // The folded kernel as the first launch of a solve, derivative pass included (see k_jacobi_strip_deriv).
@@ -946,10 +992,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold_deriv(const uint8_t *__re
                                                              const float ilambda,
                                                              unsigned *__restrict__ eps_out, const int eps_stride,
                                                              unsigned long long *__restrict__ stamps,
-                                                             const float eps_thr)
+                                                             const float eps_thr, const EpsFinish fin)
 {
     fold_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                   fA, fB, coef_w);
+                                   fA, fB, coef_w, fin);
 }
 
 } // namespace hsk

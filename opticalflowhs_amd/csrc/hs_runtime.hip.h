@@ -179,12 +179,14 @@ int eps_collect(hsflow_ctx *c, int sweeps, std::vector<unsigned> &host)
 
 // Witness slots of a speculative ITER|EPS pass (host copy): true if they prove that the early stop
 // cannot have fired before the budget ran out; *last = Eps of the final sweep.
-bool witness_proven(const unsigned *w, int slots, double epsilon, float *last)
+// last_is_exact: the last slot is the measured Eps of the final sweep (a stop there IS the budget, so it proves
+// nothing and fails nothing); otherwise every slot is a witness word and all of them must clear epsilon.
+bool witness_proven(const unsigned *w, int slots, double epsilon, float *last, bool last_is_exact)
 {
     float e = 0.f;
     for (int i = 0; i < slots; i++) {
         std::memcpy(&e, &w[i], sizeof(float));
-        if (!((double)e >= epsilon) && i != slots - 1) return false; // a stop at the very last sweep = the budget
+        if (!((double)e >= epsilon) && !(last_is_exact && i == slots - 1)) return false;
     }
     *last = e;
     return true;

@@ -101,11 +101,12 @@ int settle_pending(hsflow_ctx *c)
     HS_HIP(c, hipSetDevice(c->device));
     HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
-    if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last)) {
+    if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last, false)) {
         c->info.iterations_done = c->pend.iters;
-        c->info.last_eps = last;
+        c->info.last_eps = NAN; // not measured by an asynchronous solve; hsflow_get_info measures it on demand (c->lastl)
         return HSFLOW_OK;
     }
+    c->lastl.valid = false;
     hsflow_params q = c->pend.params;
     q.reuse_derivatives = 1; // the coefficient plane of that solve is still in place
     if (q.use_previous) {
@@ -120,6 +121,34 @@ int settle_pending(hsflow_ctx *c)
     c->info.eps_rerun = 1;
     c->info.jacobi_launches += c->pend.launches;
     return st;
+}
+
+// last_eps of an asynchronous ITER|EPS solve, on demand: the solve ran witness launches only (they prove "no early
+// stop" but measure nothing).  Its last launch left its input buffer intact, so that launch is simply run again with
+// the final sweep's Eps measured (mode 3); it rewrites the flow with the same values.
+int measure_last_eps(hsflow_ctx *c)
+{
+    if (!c->lastl.valid) return HSFLOW_OK;
+    c->lastl.valid = false;
+    const hsflow_ctx::LastLaunch &L = c->lastl;
+    const int stride = L.plan.s.tiles;
+    int st = eps_reserve(c, 2, stride);
+    if (st) return st;
+    const int b = c->cur, a = b ^ 1;
+    c->epsPtr = c->dEpsTiles;
+    c->epsStride = stride;
+    c->epsThr = L.eps_thr;
+    c->epsFin = hsk::EpsFinish{c->dEpsCounter, c->dEpsTiles, c->hEpsDev, 2, stride, 0, 0, stride};
+    const hipError_t e = launch_j(c, L.plan, 3, c->dU[a], c->dV[a], c->dU[b], c->dV[b], L.coeff, false, L.zero_in, false);
+    c->epsFin = hsk::EpsFinish{};
+    c->epsPtr = c->dEps;
+    c->epsStride = 1;
+    HS_HIP(c, e);
+    HS_HIP(c, hipStreamSynchronize(c->stream));
+    float last = 0.f;
+    std::memcpy(&last, &c->hEps[1], sizeof(float));
+    c->info.last_eps = last;
+    return HSFLOW_OK;
 }
 
 // Replays the hipGraph cached under `key`, capturing it first if needed.  `configure` sets kernel
@@ -271,8 +300,11 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
         const int n_launch = (iters + T - 1) / T;
         const int last_chunk = iters - (n_launch - 1) * T;
-        const int last_mode = 3; // two words per workgroup: the witness and the final sweep's Eps
-        const int slots = (n_launch - 1) + 2;
+        // Synchronous solves report last_eps at once: their last launch measures its final sweep (mode 3: two words
+        // per workgroup, the witness and that sweep's Eps).  Asynchronous solves run witness launches only; their
+        // last_eps is measured if and when hsflow_get_info asks for it (measure_last_eps).
+        const int last_mode = async ? 2 : 3;
+        const int slots = async ? n_launch : (n_launch - 1) + 2;
         if ((st = eps_reserve(c, slots, stride))) return st;
         const int cur0 = c->cur;
         // the first launch also does the derivative pass where the kernel can (hs_plan_launch.hip.h)
@@ -297,21 +329,30 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 const JPlan &cp = (is_last && last_chunk != T) ? tailp : plan;
                 const int a = c->cur, b = a ^ 1;
                 c->epsPtr = c->dEpsTiles + (size_t)L * stride;
+                // the last launch also folds every launch's words into the host's buffer (last workgroup reduces)
+                if (is_last)
+                    c->epsFin = hsk::EpsFinish{c->dEpsCounter, c->dEpsTiles, c->hEpsDev, slots, stride, n_launch - 1,
+                                               plan_eps_stride(kernel, plan), plan_eps_stride(kernel, last_chunk != T ? tailp : plan)};
                 prof.begin(1);
                 hipError_t e = launch_j(c, cp, is_last ? last_mode : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w, fuse);
                 prof.end();
+                c->epsFin = hsk::EpsFinish{};
                 HS_HIP(c, e);
+                if (is_last && async) { // what measure_last_eps needs
+                    c->lastl.plan = cp; c->lastl.zero_in = zero_w; c->lastl.coeff = coeff; c->lastl.eps_thr = c->epsThr;
+                }
                 c->cur = b;
                 zero_w = 0;
                 fuse = false;
                 launches++;
             }
-            return eps_collect_enqueue(c, slots, n_launch - 1, plan_eps_stride(kernel, plan),
-                                       plan_eps_stride(kernel, last_chunk != T ? tailp : plan));
+            c->epsPtr = c->dEps;
+            c->epsStride = 1;
+            return HSFLOW_OK;
         };
         if (p.use_graph && !p.profile) {
             GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
-                         c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff, c->epsThr};
+                         c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0) + (async ? 4 : 0), coeff, c->epsThr};
             auto configure = [&]() -> int {
                 HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 HS_HIP(c, launch_j(c, plan, last_mode, nullptr, nullptr, nullptr, nullptr, coeff, true));
@@ -319,8 +360,11 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 if (fuse_deriv) HS_HIP(c, launch_j(c, firstp, n_launch == 1 ? last_mode : 2, nullptr, nullptr, nullptr, nullptr, coeff, true, 0, true));
                 return HSFLOW_OK;
             };
+            const hsflow_ctx::LastLaunch keep = c->lastl;
+            bool captured = false;
             auto enqueue_n = [&](int *n) -> int {
                 launches = 0;
+                captured = true;
                 const int e = enqueue();
                 *n = launches;
                 return e;
@@ -328,12 +372,21 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             if ((st = run_captured(c, key, configure, enqueue_n, &launches))) return st;
             c->epsPtr = c->dEps;
             c->epsStride = 1;
+            if (async && !captured) { // a replay: the description of the last launch is what the capture recorded
+                const bool is_tail = last_chunk != T;
+                c->lastl = keep;
+                c->lastl.plan = is_tail ? tailp : plan;
+                c->lastl.zero_in = (n_launch == 1 && !p.use_previous) ? 1 : 0;
+                c->lastl.coeff = coeff;
+                c->lastl.eps_thr = c->epsThr;
+            }
         } else if ((st = enqueue())) {
             return st;
         }
         c->coef_valid = true;
         c->coef_mode = HSFLOW_MODE_CV;
         if (async) { // the check is owed: hsflow_synchronize (or the next call that needs results) settles it
+            c->lastl.valid = true;
             c->pend.active = true;
             c->pend.params = p;
             c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
@@ -345,7 +398,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         std::vector<unsigned> hw(c->hEps, c->hEps + slots);
 
         float last = 0.f;
-        if (witness_proven(hw.data(), slots, p.epsilon, &last)) {
+        if (witness_proven(hw.data(), slots, p.epsilon, &last, true)) {
             c->info.iterations_done = iters;
             c->info.last_eps = last;
             c->info.jacobi_launches = launches;
@@ -585,7 +638,16 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
 {
     int st = check_ctx(c, 0);
     if (st) return st;
-    if ((st = settle_pending(c))) return st; // an unverified asynchronous solve comes first
+    // An unverified asynchronous solve comes first -- unless this call repeats it exactly: while a check is owed
+    // the inputs cannot have changed (every entry point that changes frames or flow settles first), so an
+    // asynchronous solve with bit-identical parameters that starts from zero flow recomputes the very same
+    // result and leaves the very same witness words; the owed check simply passes on to it and the host does
+    // not wait for the stream (a caller that streams solves never pays a round trip per solve).
+    const bool repeat = c->pend.active && async && !c->force_exact && pp && pp->struct_size == sizeof(hsflow_params) &&
+                        !pp->use_previous && std::memcmp(pp, &c->pend.params, sizeof(hsflow_params)) == 0;
+    if (repeat) c->pend.active = false;
+    else if ((st = settle_pending(c))) return st;
+    c->lastl.valid = false;
     if (!pp || pp->struct_size != sizeof(hsflow_params))
         return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
     const hsflow_params &p = *pp;

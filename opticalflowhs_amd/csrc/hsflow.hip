@@ -142,6 +142,8 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
         HS_TRY(hipMalloc((void **)&c->dV[i], px * sizeof(float)));
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
+    HS_TRY(hipMalloc((void **)&c->dEpsCounter, sizeof(unsigned)));
+    HS_TRY(hipMemset(c->dEpsCounter, 0, sizeof(unsigned)));
     c->epsPtr = c->dEps;
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     // deterministic contents for padding columns and the initial flow
@@ -172,6 +174,7 @@ int hsflow_destroy(hsflow_ctx *c)
     for (int i = 0; i < 3; i++) hipFree(c->dE[i]);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
+    hipFree(c->dEpsCounter);
     hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
     hipFree(c->dScratch);
@@ -406,6 +409,7 @@ int hsflow_set_flow_device(hsflow_ctx *c, int pair, int row0, int nrows, const v
     int st = flow_rows_args(c, pair, row0, nrows, du, us, dv, vs);
     if (st) return st;
     if ((st = settle_pending(c))) return st; // an unverified asynchronous solve still needs the old inputs
+    c->lastl.valid = false;                  // (its last_eps can no longer be measured: the flow is about to change)
     const size_t rowb = (size_t)c->W * 4;
     const long long off = pair * c->plane + (long long)row0 * c->P;
     HS_HIP(c, hipMemcpy2DAsync(c->dU[c->cur] + off, (size_t)c->P * 4, du, us, rowb, nrows, hipMemcpyDeviceToDevice, c->stream));
@@ -458,12 +462,16 @@ int hsflow_get_frames_u8(hsflow_ctx *c, int pair, uint8_t *prev, size_t ps, uint
     return HSFLOW_OK;
 }
 
-int hsflow_get_info(hsflow_ctx *c, hsflow_info *info)
+int hsflow_get_info(hsflow_ctx *c, hsflow_info *info) { return hsflow_get_info_ex(c, info, 1); }
+
+int hsflow_get_info_ex(hsflow_ctx *c, hsflow_info *info, int measure_eps)
 {
     if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
     if (!info || info->struct_size != sizeof(hsflow_info)) return fail(c, HSFLOW_E_ARG, "info null or struct_size mismatch");
-    const int st = settle_pending(c); // iterations_done / last_eps of an asynchronous ITER|EPS solve
+    int st = settle_pending(c); // iterations_done of an asynchronous ITER|EPS solve
     if (st) return st;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HSFLOW_E_DEVICE, "hipSetDevice failed");
+    if (measure_eps && (st = measure_last_eps(c))) return st; // ... and its last_eps, measured now that somebody asks
     *info = c->info;
     return HSFLOW_OK;
 }

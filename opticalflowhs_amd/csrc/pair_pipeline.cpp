@@ -52,7 +52,8 @@ int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
     if (st) return ctx_fail(pl, s.ctx, st, "hsflow_synchronize");
     hsflow_info info;
     info.struct_size = sizeof(info);
-    if ((st = hsflow_get_info(s.ctx, &info))) return ctx_fail(pl, s.ctx, st, "hsflow_get_info");
+    // (without last_eps: an asynchronous ITER|EPS solve measures it only on demand -- hsflow_pipeline_info)
+    if ((st = hsflow_get_info_ex(s.ctx, &info, 0))) return ctx_fail(pl, s.ctx, st, "hsflow_get_info_ex");
     if (info.eps_rerun) { // the solve was repeated exactly: what the queued download copied is stale
         if ((st = hsflow_get_flow(s.ctx, 0, s.u, s.us, s.v, s.vs))) return ctx_fail(pl, s.ctx, st, "hsflow_get_flow");
     }
@@ -149,8 +150,14 @@ int hsflow_pipeline_info(hsflow_pipeline *pl, uint64_t ticket, hsflow_info *out)
     if (!out || out->struct_size != sizeof(hsflow_info)) return pfail(pl, HSFLOW_E_ARG, "info null or struct_size mismatch");
     int st = hsflow_pipeline_wait(pl, ticket);
     if (st) return st;
-    const hsflow_pipeline::Slot &s = pl->slots[ticket % pl->slots.size()];
+    hsflow_pipeline::Slot &s = pl->slots[ticket % pl->slots.size()];
     if (!s.has_done || s.done_ticket != ticket) return pfail(pl, HSFLOW_E_STATE, "the slot of that ticket has been reused by a later pair");
+    if (!s.busy) { // the slot's context still holds that solve: last_eps can be measured now (NaN otherwise)
+        hsflow_info info;
+        info.struct_size = sizeof(info);
+        if ((st = hsflow_get_info_ex(s.ctx, &info, 1))) return ctx_fail(pl, s.ctx, st, "hsflow_get_info_ex");
+        s.done.last_eps = info.last_eps;
+    }
     *out = s.done;
     return HSFLOW_OK;
 }

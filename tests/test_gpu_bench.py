@@ -27,29 +27,52 @@ def test_bench_single_gpu_line(gpu_ok):
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
-    for k in KEYS + ["cpu_baseline"]:
+    for k in KEYS + ["cpu_baseline", "ms_per_step_min", "ms_per_step_median", "ms_per_step_max", "other_termination"]:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "Mpix*iter/s" and d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["config"]["workload"].startswith("1920x1080") and "model" not in d["config"]
+    # the headline is the reference's own call form (ITER|EPS, eps 1e-6), ITER beside it; no early stop on this pair
+    assert d["config"]["termination"].startswith("ITER|EPS") and d["config"]["iterations_done"] == 100 and d["config"]["eps_rerun"] == 0
+    assert d["other_termination"]["termination"] == "ITER" and d["other_termination"]["ms_per_step"] > 0
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and len(d["ms_per_step_blocks"]) == 5
+    assert d["ms_per_step_blocks"][0] == d["ms_per_step"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # the bound that binds the multi-sweep kernel is VALU issue: a fraction in (0, 1], recomputable from its parts
+    assert rf["bound"] == "valu" and rf["unit"] == "Tlane-op/s" and 0 < rf["frac"] <= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert rf["traffic"] and rf["traffic"] < rf["algorithmic_bytes_per_launch"]  # the committed PMC summary of this workload
+    vi = rf["valu_issue"]
+    c = vi["constants"]
+    peak = c["simds"] * 64.0 / c["cycles_per_wave64_op_measured"] * c["clock_ghz_measured"] * 1e9 / 1e12
+    assert abs(rf["peak"] - peak) < 1e-9 * peak
+    ach = vi["op_slots_per_pixel_sweep"] * 1920 * 1080 * rf["sweeps_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12
+    assert abs(rf["achieved"] - ach) < 1e-6 * ach
+    assert abs(vi["ideal_us_per_step"] / vi["jacobi_kernel_us_per_step"] - rf["frac"]) < 1e-6
+    assert rf["traffic_measured_in_run"] is False and (rf["traffic"] is None or rf["traffic"] < rf["hbm_algorithmic"]["bytes_per_launch"])
+    assert rf["hbm_algorithmic"]["bytes_per_pixel_sweep"] == 28.0
     assert abs(d["value"] - 1920 * 1080 * 100 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mpix*iter/s"
 
 
 def test_bench_two_ranks_rehearsal(gpu_ok):
+    """The N > 1 line as the driver's SCALE run would produce it, rehearsed with two ranks sharing the one card
+    over gloo (halo rows staged through the host): the headline plus the C4 pipeline and the C5 slab
+    measurements (shrunk: 16 pairs, a 2048^2 frame, 70 sweeps), the slab result checked bit for bit."""
     env = dict(os.environ, HSFLOW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3"],
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--c4-pairs", "16", "--c5-size", "2048", "--c5-iters", "70", "--c5-halo", "16"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
     assert abs(d["value"] - 2 * 1920 * 1080 * 100 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    c4, c5 = d["c4_pipeline"], d["c5_slab"]
+    assert c4["pairs_total"] == 16 and c4["pairs_this_rank"] == 8 and c4["value"] > 0 and c4["collective"].startswith("none")
+    assert c5["owned_rows_bit_identical_to_band_solve"] is True
+    assert c5["plain"]["exchanges"] == 4 and c5["overlap"]["exchanges"] == 4 and c5["plain"]["value"] > 0 and c5["overlap"]["value"] > 0
 
 
 @pytest.mark.parametrize("extra", [[], ["--overlap"]])

@@ -230,7 +230,25 @@ def test_scaled_state_matches_canonical_arithmetic_down_to_denormals(hs, gpu_ok)
                 assert np.array_equal(g[fin], r[fin]), (lam, kern, kw, float(np.abs(r[fin]).max()))
 
 
-def test_eps_termination_matches_oracle(hs, gpu_ok):
+def check_stop(name, oracle, A, B, lam, got, n_gpu, want, n_oracle, u0=None, v0=None, done_before=0):
+    """Flow of an EPS-terminated solve against the oracle.  The stopping sweep is integer work and must be the
+    oracle's, except where a sweep's Eps lies within fp32 rounding of epsilon (the oracle measures its own x87
+    iterates, the GPU its fp32 ones): then it may differ by ONE, and the flow is compared with the oracle run
+    to the GPU's sweep count instead -- never skipped.  How often that happened goes into the parity report."""
+    assert abs(n_gpu - n_oracle) <= 1, (name, n_gpu, n_oracle)
+    _report.setdefault("_eps_stop_sweep", {"same": 0, "off_by_one": 0, "off_by_one_cases": []})
+    if n_gpu == n_oracle:
+        _report["_eps_stop_sweep"]["same"] += 1
+        check(name, got, want)
+        return
+    _report["_eps_stop_sweep"]["off_by_one"] += 1
+    _report["_eps_stop_sweep"]["off_by_one_cases"].append(name)
+    kw = dict(use_previous=True, velx=u0, vely=v0) if u0 is not None else {}
+    uo, vo = oracle.calc_optical_flow_hs(A, B, lam, n_gpu - done_before, term_type=ITER, **kw)
+    check(name + "_at_gpu_count", got, (uo, vo))
+
+
+def test_eps_termination_matches_oracle(hs, oracle, gpu_ok):
     d = np.load(os.path.join(GOLDEN, "eps_48x40_l0.002_e1e-3.npz"))
     for kw in (dict(kernel=hs.KERNEL_SIMPLE), dict(kernel=hs.KERNEL_FUSED), dict(kernel=hs.KERNEL_FUSED, fuse_steps=5),
                dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_STRIP, fuse_steps=7, strip_rows=2),
@@ -238,24 +256,22 @@ def test_eps_termination_matches_oracle(hs, gpu_ok):
         u, v, info = gpu_solve(hs, d["A"], d["B"], 0.002, 500, eps=1e-3, tt=ITER | EPS, **kw)
         assert abs(info["iterations_done"] - int(d["iters"])) <= 1, info
         assert info["last_eps"] < 1e-3
-        if info["iterations_done"] == int(d["iters"]):
-            check("eps_stop_%s_%d" % (kw["kernel"], kw.get("fuse_steps", 0)), (u, v), (d["u"], d["v"]))
+        check_stop("eps_stop_%s_%d" % (kw["kernel"], kw.get("fuse_steps", 0)), oracle, d["A"], d["B"], 0.002, (u, v), info["iterations_done"],
+                   (d["u"], d["v"]), int(d["iters"]))
     # identical frames: stops after the first sweep with zero flow (K1)
     A = d["A"]
     u, v, info = gpu_solve(hs, A, A, 0.1, 100, eps=float(np.float32(1e-6)), tt=ITER | EPS)
     assert info["iterations_done"] == 1 and not u.any() and not v.any()
     # EPS only
     u2, v2, info2 = gpu_solve(hs, d["A"], d["B"], 0.002, 0, eps=1e-3, tt=EPS)
-    assert abs(info2["iterations_done"] - int(d["iters"])) <= 1
+    check_stop("eps_only_stop", oracle, d["A"], d["B"], 0.002, (u2, v2), info2["iterations_done"], (d["u"], d["v"]), int(d["iters"]))
     # ITER|EPS continuing from a previous flow: 5 sweeps, then the rest with the early stop
     with hs.HSFlow(48, 40, 1, own_stream=True) as ctx:
         ctx.set_frames(d["A"], d["B"])
         ctx.solve(lam=0.002, max_iter=5, term_type=ITER)
         info3 = ctx.solve(lam=0.002, max_iter=495, epsilon=1e-3, term_type=ITER | EPS, use_previous=True)
         u3, v3 = ctx.flow()
-    assert abs(info3["iterations_done"] + 5 - int(d["iters"])) <= 1
-    if info3["iterations_done"] + 5 == int(d["iters"]):
-        check("eps_stop_use_previous", (u3, v3), (d["u"], d["v"]))
+    check_stop("eps_stop_use_previous", oracle, d["A"], d["B"], 0.002, (u3, v3), info3["iterations_done"] + 5, (d["u"], d["v"]), int(d["iters"]))
     # budget reached before the threshold: plain ITER result
     u4, v4, info4 = gpu_solve(hs, d["A"], d["B"], 0.002, 40, eps=1e-3, tt=ITER | EPS)
     u5, v5, _ = gpu_solve(hs, d["A"], d["B"], 0.002, 40, tt=ITER)
@@ -479,6 +495,97 @@ def test_full_16384_frame_bands_against_oracle(hs, oracle, gpu_ok):
         check("c5_full_band_%d" % lo, (u[lo:hi], v[lo:hi]), (uo[lo - a:hi - a], vo[lo - a:hi - a]))
 
 
+def test_c5_strip_500_sweeps_against_oracle_and_slab(hs, oracle, gpu_ok):
+    """BASELINE config C5 at its own sweep count: the 16384 x 512 strip of the seed-3 frame that
+    straddles the boundary between the first two of eight row slabs (frame rows 1792..2303, boundary at 2048),
+    lambda 1, 500 sweeps, against the oracle's OpenMP form on the same strip (x87-vs-fp32 drift over 500 sweeps
+    is what this pins: bar 1e-4 RMS); and the same strip through the row-slab driver with two ranks (threads,
+    cut exactly at that boundary, halo 16: 31 exchanges) -- bit-identical to the one-context solve."""
+    import threading
+    from opticalflowhs_amd import slab
+    from test_gpu_slab import LocalDist
+    W, H, it = 16384, 512, 500
+    A, B = synth.translating_pair(W, 16384, seed=3, row0=1792, rows=H)
+    uo, vo = oracle.calc_optical_flow_hs(A, B, 1.0, it, term_type=ITER, threads=0)
+    u, v, info = gpu_solve(hs, A, B, 1.0, it)
+    assert info["iterations_done"] == it and info["kernel"] == hs.KERNEL_STRIP
+    check("c5_strip_16384x512_i500", (u, v), (uo, vo))
+    LocalDist.boxes = {}
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            s = slab.SlabSolver(LocalDist(rank), rank, 2, W, H, 16, lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0))
+            r0, r1 = s.local_frame_rows()
+            s.set_frames(A[r0:r1], B[r0:r1])
+            n_ex = s.solve(1.0, it)
+            res[rank] = (s.lo, s.hi, n_ex) + s.owned_flow()
+            s.close()
+        except Exception as e:  # surfaced in the main thread
+            errs.append((rank, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in ths]
+    [t.join(600) for t in ths]
+    assert not errs and len(res) == 2, errs
+    for rank in range(2):
+        lo, hi, n_ex, ur, vr = res[rank]
+        assert (lo, hi) == ((0, 256), (256, 512))[rank] and n_ex == 31
+        assert np.array_equal(ur, u[lo:hi]) and np.array_equal(vr, v[lo:hi]), rank
+
+
+def test_c4_shaped_batch_and_pipeline(hs, oracle, gpu_ok):
+    """BASELINE config C4 at its per-GPU shape: 1920 x 1080 pairs with seeds 1000 + i, lambda 1, 100 sweeps --
+    (1) eight of them resident in ONE context (one batch launch sequence), (2) the same pairs from page-locked
+    host memory through the pair pipeline at depth 4 (uploads / downloads beside the solves).  Every pair must
+    equal the single-pair context bit for bit; two sampled pairs are compared with the oracle."""
+    W, H, N, it = 1920, 1080, 8, 100
+    pairs = [synth.translating_pair(W, H, seed=1000 + i) for i in range(N)]
+    single = []
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        for A, B in pairs:
+            ctx.set_frames(A, B)
+            ctx.solve(lam=1.0, max_iter=it, term_type=ITER, use_graph=True)
+            single.append(ctx.flow())
+    for i in (0, 5):
+        uo, vo = oracle.calc_optical_flow_hs(pairs[i][0], pairs[i][1], 1.0, it, term_type=ITER, threads=0)
+        check("c4_pair_%d" % i, single[i], (uo, vo))
+    with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+        for i, (A, B) in enumerate(pairs):
+            ctx.set_frames(A, B, pair=i)
+        info = ctx.solve(lam=1.0, max_iter=it, term_type=ITER, use_graph=True)
+        assert info["iterations_done"] == it and info["n_pairs"] == N
+        for i in range(N):
+            u, v = ctx.flow(i)
+            assert np.array_equal(u, single[i][0]) and np.array_equal(v, single[i][1]), i
+    with hs.PairPipeline(W, H, depth=4) as pl:
+        bufs = []
+        for A, B in pairs:
+            a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)
+            a[...], b[...] = A, B
+            u, v = hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)
+            u.fill(np.nan)
+            v.fill(np.nan)
+            pl.submit(a, b, u, v, lam=1.0, max_iter=it, use_graph=True)
+            bufs.append((u, v))
+        pl.drain()
+        for i, (u, v) in enumerate(bufs):
+            assert np.array_equal(u, single[i][0]) and np.array_equal(v, single[i][1]), i
+        # the same through the reference's own termination criteria (ITER|EPS, eps 1e-6: never fires here)
+        eps6 = float(np.float32(1e-6))
+        t = pl.submit(hs_pin(hs, pairs[3][0]), hs_pin(hs, pairs[3][1]), bufs[0][0], bufs[0][1], lam=1.0, max_iter=it, epsilon=eps6,
+                      term_type=ITER | EPS, use_graph=True)
+        i3 = pl.info(t)
+        assert i3["iterations_done"] == it and i3["eps_rerun"] == 0
+        assert np.array_equal(bufs[0][0], single[3][0]) and np.array_equal(bufs[0][1], single[3][1])
+
+
+def hs_pin(hs, arr):
+    out = hs.pinned_empty(arr.shape, arr.dtype)
+    out[...] = arr
+    return out
+
+
 def test_randomized_shapes_parameters_kernels(hs, oracle, gpu_ok):
     """Seeded random sweep over frame shapes (including images narrower than the halo, odd widths,
     single rows / columns), lambda, sweep counts and every kernel with random tuning knobs: parity
@@ -552,9 +659,7 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
             uo2, vo2, n2, e2 = oracle.calc_optical_flow_hs(A, B, 0.7, it, near, ITER | EPS, return_info=True)
             slow = ctx.solve(lam=0.7, max_iter=it, epsilon=near, term_type=ITER | EPS)
             u2, v2 = ctx.flow()
-            assert abs(slow["iterations_done"] - n2) <= 1, (frac, slow["iterations_done"], n2)
-            if slow["iterations_done"] == n2:
-                check("iter_eps_near_%g" % frac, (u2, v2), (uo2, vo2))
+            check_stop("iter_eps_near_%g" % frac, oracle, A, B, 0.7, (u2, v2), slow["iterations_done"], (uo2, vo2), n2)
         # the same pass replayed from a hipGraph (kernels, Eps reduction and read-back in one graph)
         for rep in range(3):
             g = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, use_graph=True)
@@ -572,10 +677,8 @@ def test_iter_eps_witness_and_fallback_regimes(hs, oracle, gpu_ok):
         stop = ctx.solve(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS, use_graph=True)
         u3, v3 = ctx.flow()
         assert stop["eps_rerun"] == 1
-        assert abs(stop["iterations_done"] - n3) <= 1
         assert stop["jacobi_launches"] > plain["jacobi_launches"]          # witness pass + exact pass + re-run
-        if stop["iterations_done"] == n3:
-            check("iter_eps_early_stop", (u3, v3), (uo3, vo3))
+        check_stop("iter_eps_early_stop", oracle, A, B, 0.7, (u3, v3), stop["iterations_done"], (uo3, vo3), n3)
 
 
 def test_cached_graphs_survive_growing_eps_buffers(hs, gpu_ok):

@@ -215,3 +215,70 @@ def test_pipeline_runs_the_cpu_routes_preprocessing_on_the_device(hs, oracle, gp
         assert np.sqrt(np.mean((u.astype(np.float64) - uo) ** 2)) <= RMS_TOL and np.sqrt(np.mean((v.astype(np.float64) - vo) ** 2)) <= RMS_TOL
         with pytest.raises(ValueError):
             pl.submit(A[:, :, 0], B, u, v, frames="bgr", **crit)
+
+
+def test_repeated_async_iter_eps_solves_pass_the_owed_check_on(hs, oracle, gpu_ok):
+    """hsflow_solve_async with the reference's ITER|EPS criteria owes an early-stop check.  A following
+    asynchronous solve with bit-identical parameters (zero start) takes that check over instead of waiting for
+    the stream; whatever settles it in the end must leave exactly what a synchronous solve leaves -- also when
+    the witness fails and the exact pass has to run, and when the parameters change in between."""
+    import time
+    W, H, it = 700, 300, 57
+    A, B = synth.translating_pair(W, H, seed=21, dx=1.25, dy=-0.75)
+    eps6 = float(np.float32(1e-6))
+    EPS = 2
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        want = ctx.solve(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, use_graph=True)
+        u0, v0 = ctx.flow()
+        p = ctx.make_params(lam=0.7, max_iter=it, epsilon=eps6, term_type=ITER | EPS, use_graph=True)
+        for _ in range(3):
+            ctx.solve_async(p)
+        ctx.synchronize()                       # warm
+        t0 = time.perf_counter()
+        for _ in range(40):
+            ctx.solve_async(p)
+        t_enqueue = time.perf_counter() - t0
+        ctx.synchronize()
+        t_all = time.perf_counter() - t0
+        got = ctx.info()
+        u, v = ctx.flow()
+        # (last_eps: the asynchronous solves measured nothing; info() ran the last launch again to get it)
+        assert got["iterations_done"] == it and got["eps_rerun"] == 0 and got["last_eps"] == want["last_eps"]
+        assert np.array_equal(u, u0) and np.array_equal(v, v0)
+        ctx.solve_async(p)
+        assert ctx.info()["last_eps"] == want["last_eps"]
+        u, v = ctx.flow()                       # the measuring launch rewrote the same flow
+        assert np.array_equal(u, u0) and np.array_equal(v, v0)
+        assert t_enqueue < 0.8 * t_all or t_all < 2e-3, (t_enqueue, t_all)   # the host ran ahead of the device
+        # witness fails (epsilon above the final Eps): the repeats still end in the exact result
+        over = float(want["last_eps"]) * 3.0
+        ref = ctx.solve(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS, use_graph=True)
+        ur, vr = ctx.flow()
+        assert ref["eps_rerun"] == 1 and ref["iterations_done"] < it
+        q = ctx.make_params(lam=0.7, max_iter=it, epsilon=over, term_type=ITER | EPS, use_graph=True)
+        for _ in range(5):
+            ctx.solve_async(q)
+        got = ctx.info()                        # settles: exact pass
+        u, v = ctx.flow()
+        assert got["eps_rerun"] == 1 and got["iterations_done"] == ref["iterations_done"]
+        assert np.array_equal(u, ur) and np.array_equal(v, vr)
+        # a change of parameters in between settles the old solve first; each result is its own
+        ctx.solve_async(p)
+        r = ctx.make_params(lam=0.3, max_iter=it, epsilon=eps6, term_type=ITER | EPS, use_graph=True)
+        ctx.solve_async(r)
+        ctx.solve_async(r)
+        u3, v3 = ctx.flow()
+        i3 = ctx.info()
+        uo, vo = oracle.calc_optical_flow_hs(A, B, 0.3, it, eps6, ITER | EPS)
+        assert i3["iterations_done"] == it
+        assert np.sqrt(np.mean((u3.astype(np.float64) - uo) ** 2)) <= RMS_TOL and np.sqrt(np.mean((v3.astype(np.float64) - vo) ** 2)) <= RMS_TOL
+        # warm starts are never carried over (the state moves on): two use_previous solves = 2 x the sweeps
+        ctx.solve(lam=0.3, max_iter=10, term_type=ITER)
+        w = ctx.make_params(lam=0.3, max_iter=10, epsilon=eps6, term_type=ITER | EPS, use_previous=True)
+        ctx.solve_async(w)
+        ctx.solve_async(w)
+        u4, v4 = ctx.flow()
+        ctx.solve(lam=0.3, max_iter=30, term_type=ITER)
+        u5, v5 = ctx.flow()
+        assert np.array_equal(u4, u5) and np.array_equal(v4, v5)

@@ -2,7 +2,7 @@
 """Turns gpurun_out/prof_<tag>/ (tools/profile_gpu.sh) into committed summaries under profiles/:
    profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary
    profiles/<tag>_traffic.json          HBM bytes per Jacobi launch from the PMC passes
-   profiles/traffic_latest.json         the same, read by bench.py for roofline.traffic
+   (bench.py reads every profiles/*_traffic.json and takes the one whose kernel, launch shape and frame size match)
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of a wide
 coalesced read stream, so it is doubled; WRITE_SIZE is taken as is.  Both counters are in KiB."""
 import csv
@@ -40,7 +40,9 @@ def main():
     shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(ROOT, "profiles", "%s_bench_under_rocprof.json" % tag))
     kern = bench["roofline"]["kernel"] + "<"  # "k_jacobi_strip<": not the first-launch variant k_jacobi_strip_deriv<
     out = {"tag": tag, "kernel": kern[:-1], "width": bench["config"]["width"], "height": bench["config"]["height"],
-           "fuse_steps": bench["config"]["fuse_steps"], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
+           "pairs": bench["config"]["pairs_per_gpu"], "fuse_steps": bench["config"]["fuse_steps"],
+           "rows_per_lane_or_groups": bench["config"]["rows_per_lane_or_groups"], "threads": bench["config"]["threads"],
+           "tiles_per_launch": bench["config"]["tiles_per_launch"], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
     fetch = find(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"))
     write = find(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"))
     if fetch and write:
@@ -54,9 +56,6 @@ def main():
                         "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0})
     with open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1)
-    # traffic_latest.json follows the default bench workload only; bench.py also searches every *_traffic.json
-    if "hbm_bytes_per_launch" in out and out.get("width") == 1920 and out.get("height") == 1080:
-        shutil.copy(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), os.path.join(ROOT, "profiles", "traffic_latest.json"))
     print(json.dumps(out, indent=1))
     if stats:
         print(open(stats).read()[:1500])
