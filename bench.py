@@ -265,8 +265,17 @@ def main():
     head_p, side_p = (p_iter, p_ieps) if args.iter_only else (p_ieps, p_iter)
     head_name, side_name = ("ITER", "ITER|EPS (eps 1e-6)") if args.iter_only else ("ITER|EPS (eps 1e-6)", "ITER")
     step = stepper(head_p)
-    for _ in range(args.warmup):
+    # Warm-up: --warmup untimed steps, and further untimed steps until WARM_SECONDS have passed -- an idle MI355X needs
+    # ~30 ms of back-to-back work to reach the clock it then holds (profiles/r02_clock_ramp.txt: 0.196 -> 0.175 ms per
+    # step over the first 150 steps), and a timed region that starts inside that ramp measures the ramp.
+    WARM_SECONDS = 0.1
+    t_w = time.perf_counter()
+    n_warm = 0
+    while n_warm < args.warmup or time.perf_counter() - t_w < WARM_SECONDS:
         step()
+        n_warm += 1
+        if n_warm % 16 == 0:
+            torch.cuda.synchronize()   # keep the host from running far ahead of the device while watching the clock
     torch.cuda.synchronize()
 
     # THE timed region of the contract: exactly --steps steps between barrier + synchronize, max over ranks
@@ -370,6 +379,7 @@ def main():
     out = {
         "metric": "Mpixel*iterations/sec (Horn-Schunck: derivative pass + Jacobi u/v sweeps, frames resident in HBM)",
         "value": value, "unit": "Mpix*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "warmup_steps_run": n_warm,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, %s termination"

@@ -69,8 +69,6 @@ struct hsflow_ctx {
     int epsStride = 1;          // words per sweep: one per workgroup (strip / fold), else 1
     unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
     size_t epsTilesCap = 0;
-    hsk::EpsFinish epsFin{};   // handed to every strip / fold launch; counter != NULL only for the last launch of a witness pass
-    unsigned *dEpsCounter = nullptr; // its ticket counter (zero between launches)
     float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;
@@ -84,6 +82,7 @@ struct hsflow_ctx {
         bool active = false;
         hsflow_params params;
         int iters = 0, slots = 0, launches = 0, cur0 = 0;
+        int stride = 1, n_first = 0, cnt_first = 0, cnt_last = 0; // layout of its witness words (k_eps_reduce's arguments)
     } pend;
     // what it takes to measure last_eps of an asynchronous ITER|EPS solve on demand (hsflow_get_info): its last
     // launch again, from the input buffer that launch left intact, with the final sweep's Eps measured

@@ -61,48 +61,6 @@ struct StripGeom {
     int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
 };
 
-// The last launch of a witness pass also reduces the per-workgroup words of ALL the pass's launches to one word
-// per row, straight into the host's page-locked buffer -- no reduction kernel, no kernel boundary behind the solve.
-// "Last workgroup reduces": every workgroup publishes its word(s) with write-through (sc1) stores, drains them,
-// then takes a ticket from an agent-scope counter; the workgroup whose ticket is the last one reads every row
-// with sc1 loads (the words of earlier launches are visible across the kernel boundary, those of this launch
-// through the drained write-through stores and the ticket: MI355X_MICROARCH.md, inter-workgroup visibility,
-// "one lane of each storing workgroup ... the workgroup whose add came last").  counter == nullptr: not wanted.
-struct EpsFinish {
-    unsigned *counter;        // zero between launches; the last workgroup resets it
-    const unsigned *rows;     // [n_rows][stride] words
-    unsigned *host_out;       // device address of page-locked host memory: n_rows words
-    int n_rows, stride;
-    int n_first, cnt_first, cnt_last; // rows [0, n_first) hold cnt_first valid words, the others cnt_last
-};
-
-// called by wavefront 0 of every workgroup after lane 0 has stored this workgroup's words (write-through)
-__device__ __forceinline__ void eps_finish(const EpsFinish &f, int lane)
-{
-    unsigned ticket = 0;
-    if (lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the words have left this CU before the ticket is drawn
-        ticket = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-    if (ticket != gridDim.x - 1) return;
-    for (int row = 0; row < f.n_rows; row++) {
-        const int n = row < f.n_first ? f.cnt_first : f.cnt_last;
-        const unsigned *src = f.rows + (size_t)row * f.stride;
-        unsigned m = 0;
-        for (int i = lane; i < n; i += 64) {
-            const unsigned x = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = x > m ? x : m; // bit patterns of non-negative floats order like unsigned integers
-        }
-        const float y = wave_max_nonneg(__uint_as_float(m));
-        if (lane == 0) f.host_out[row] = __float_as_uint(y);
-    }
-    if (lane == 0) {
-        __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-    }
-}
-
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
 __device__ __forceinline__ int mirror_index(int i, int n)
 {
@@ -273,8 +231,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
                                                         const float eps_thr, const uint8_t *__restrict__ fA,
-                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w,
-                                                        const EpsFinish fin)
+                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
 {
     // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
     // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
@@ -517,15 +474,22 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
         float e = 0.f;
         if (R == 1) {
+            const float o0 = uP[0].x;
             HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ, cf[0]);
+            if (EM == 2 && (rowcore & 1u))
+                seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(o0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
         } else {
             constexpr int R1 = R > 1 ? 1 : 0, RM = R > 2 ? R - 2 : 0;
             const f2 o0uP = uP[0], o0uQ = uQ[0], o0vP = vP[0], o0vQ = vQ[0];                 // old first row
             const f2 oNuP = uP[R - 1], oNuQ = uQ[R - 1], oNvP = vP[R - 1], oNvQ = vQ[R - 1]; // old last row
             HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
+            // witness: did u change by >= eps_thr at column x0 of the strip's first row (a core row) in any lane?
+            // Old and new value are both in registers at this point (the old first row is kept for row 1 anyway).
+            if (EM == 2 && (rowcore & 1u))
+                seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(o0uP.x, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
             if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
             else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
-            if (EM == 2 || s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
+            if (s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
             f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
@@ -536,7 +500,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
             }
         }
-        if (R == 1 && (EM == 2 || s + 1 < g.T)) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
+        if (R == 1 && s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
         if (EM == 1 && EPS == 3) { // the one measured sweep of a witness launch: folded after the loop
             e = wave_max_nonneg(lanecore ? e : 0.f) * unscale;
             if (lane == 0) eps_lds[16 + w] = e;
@@ -549,14 +513,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 x = wave_max_nonneg(x);
                 if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
             }
-        }
-        if (EM == 2 && (rowcore & 1u)) {
-            // witness, read back from the exchange buffers at the end of the sweep (no register is kept
-            // for it): slot 0 of this wavefront holds its first row of u, new in buffer (s+1)&1 and old
-            // in buffer s&1; component x is column x0, an image column wherever lanecore holds
-            const float nu = *(const float *)(ex + ((size_t)(((s + 1) & 1) * NW + w) * 4) * 64 + lane);
-            const float ou = *(const float *)(ex + ((size_t)((s & 1) * NW + w) * 4) * 64 + lane);
-            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(ou, nu)) >= thr_s) != 0 ? 1 : 0;
         }
 #if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
         if (!P2P && s + 1 < g.T) __syncthreads();
@@ -596,12 +552,11 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) __hip_atomic_store(eps_out + blockIdx.x, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
-                if (lane == 0) __hip_atomic_store(eps_out + (size_t)eps_stride + blockIdx.x, __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
             }
-            if (fin.counter) eps_finish(fin, lane);
         }
     }
 #undef HS_ROW
@@ -650,10 +605,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         const float ilambda,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
-                                                        const float eps_thr, const EpsFinish fin)
+                                                        const float eps_thr)
 {
     strip_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                     nullptr, nullptr, nullptr, fin);
+                                     nullptr, nullptr, nullptr);
 }
 
 // First launch of a solve with the derivative pass folded in: reads the two frames instead of the packed
@@ -669,10 +624,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__r
                                                               const float ilambda,
                                                               unsigned *__restrict__ eps_out, const int eps_stride,
                                                               unsigned long long *__restrict__ stamps,
-                                                              const float eps_thr, const EpsFinish fin)
+                                                              const float eps_thr)
 {
     strip_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                    fA, fB, coef_w, fin);
+                                    fA, fB, coef_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -707,8 +662,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps,
                                                        const float eps_thr, const uint8_t *__restrict__ fA,
-                                                       const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w,
-                                                       const EpsFinish fin)
+                                                       const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
 {
     extern __shared__ __attribute__((aligned(16))) float4 ex[]; // [2 buf][NW][2 half][2 plane][32], then Eps
     unsigned long long st0 = 0, sr0 = 0, st1 = 0, st2 = 0;
@@ -866,7 +820,11 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             constexpr int R1 = R > 1 ? 1 : 0;
             HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
         }
-        if (EM == 2 || s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+        // witness (k_jacobi_strip explains it): old and new value of the published row -- register row 0 of each
+        // half -- at column x0, both in registers here
+        if (EM == 2)
+            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(puP.x, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
+        if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
 #pragma unroll
         for (int r = 1; r < R; r++) {
             const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
@@ -874,13 +832,6 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             if (r == R - 1) HF_ROW(r, puP, puQ, pvP, pvQ, iuP, iuQ, ivP, ivQ);
             else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
             puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
-        }
-        if (EM == 2) {
-            // witness (k_jacobi_strip explains it): old and new value of the published row -- register
-            // row 0 of each half -- at column x0 come back from the two exchange buffers
-            const float nu = *(const float *)(HF_SLOT((s + 1) & 1, w, lower ? 1 : 0) + hl);
-            const float ou = *(const float *)(HF_SLOT(s & 1, w, lower ? 1 : 0) + hl);
-            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(ou, nu)) >= thr_s) != 0 ? 1 : 0;
         }
         if (EM == 1 && EPS == 3) {
             e = wave_max(e) * unscale;
@@ -930,12 +881,11 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) __hip_atomic_store(eps_out + blockIdx.x, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
-                if (lane == 0) __hip_atomic_store(eps_out + (size_t)eps_stride + blockIdx.x, __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
             }
-            if (fin.counter) eps_finish(fin, lane);
         }
     }
 #undef HF_ROW
@@ -974,10 +924,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        const float ilambda,
                                                        unsigned *__restrict__ eps_out, const int eps_stride,
                                                        unsigned long long *__restrict__ stamps,
-                                                       const float eps_thr, const EpsFinish fin)
+                                                       const float eps_thr)
 {
     fold_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                    nullptr, nullptr, nullptr, fin);
+                                    nullptr, nullptr, nullptr);
 }
 
 // The folded kernel as the first launch of a solve, derivative pass included (see k_jacobi_strip_deriv).
@@ -992,10 +942,10 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold_deriv(const uint8_t *__re
                                                              const float ilambda,
                                                              unsigned *__restrict__ eps_out, const int eps_stride,
                                                              unsigned long long *__restrict__ stamps,
-                                                             const float eps_thr, const EpsFinish fin)
+                                                             const float eps_thr)
 {
     fold_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
-                                   fA, fB, coef_w, fin);
+                                   fA, fB, coef_w);
 }
 
 } // namespace hsk

@@ -235,7 +235,7 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
     }
     if (configure_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
-                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr, c->epsFin);
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
 }
 
@@ -276,7 +276,7 @@ hipError_t launch_strip_deriv_t(const hsflow_ctx *c, const StripPlan &p, const f
     }
     if (configure_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi,
-                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr, c->epsFin);
+                       uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
 }
 

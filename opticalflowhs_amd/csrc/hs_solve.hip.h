@@ -99,6 +99,12 @@ int settle_pending(hsflow_ctx *c)
     if (!c->pend.active) return HSFLOW_OK;
     c->pend.active = false;
     HS_HIP(c, hipSetDevice(c->device));
+    // the witness words of that solve's launches are still per workgroup: an asynchronous solve enqueues no
+    // reduction (a stream of solves would pay a kernel and a boundary per solve for words nobody reads); now
+    // that somebody wants the verdict, reduce them into the host's buffer and wait
+    c->epsStride = c->pend.stride;
+    int st0 = eps_collect_enqueue(c, c->pend.slots, c->pend.n_first, c->pend.cnt_first, c->pend.cnt_last);
+    if (st0) return st0;
     HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
     if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last, false)) {
@@ -138,12 +144,9 @@ int measure_last_eps(hsflow_ctx *c)
     c->epsPtr = c->dEpsTiles;
     c->epsStride = stride;
     c->epsThr = L.eps_thr;
-    c->epsFin = hsk::EpsFinish{c->dEpsCounter, c->dEpsTiles, c->hEpsDev, 2, stride, 0, 0, stride};
     const hipError_t e = launch_j(c, L.plan, 3, c->dU[a], c->dV[a], c->dU[b], c->dV[b], L.coeff, false, L.zero_in, false);
-    c->epsFin = hsk::EpsFinish{};
-    c->epsPtr = c->dEps;
-    c->epsStride = 1;
     HS_HIP(c, e);
+    if ((st = eps_collect_enqueue(c, 2, 0, 0, stride))) return st; // (resets epsPtr / epsStride)
     HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
     std::memcpy(&last, &c->hEps[1], sizeof(float));
@@ -329,14 +332,9 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 const JPlan &cp = (is_last && last_chunk != T) ? tailp : plan;
                 const int a = c->cur, b = a ^ 1;
                 c->epsPtr = c->dEpsTiles + (size_t)L * stride;
-                // the last launch also folds every launch's words into the host's buffer (last workgroup reduces)
-                if (is_last)
-                    c->epsFin = hsk::EpsFinish{c->dEpsCounter, c->dEpsTiles, c->hEpsDev, slots, stride, n_launch - 1,
-                                               plan_eps_stride(kernel, plan), plan_eps_stride(kernel, last_chunk != T ? tailp : plan)};
                 prof.begin(1);
                 hipError_t e = launch_j(c, cp, is_last ? last_mode : 2, c->dU[a], c->dV[a], c->dU[b], c->dV[b], coeff, false, zero_w, fuse);
                 prof.end();
-                c->epsFin = hsk::EpsFinish{};
                 HS_HIP(c, e);
                 if (is_last && async) { // what measure_last_eps needs
                     c->lastl.plan = cp; c->lastl.zero_in = zero_w; c->lastl.coeff = coeff; c->lastl.eps_thr = c->epsThr;
@@ -346,9 +344,13 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 fuse = false;
                 launches++;
             }
-            c->epsPtr = c->dEps;
-            c->epsStride = 1;
-            return HSFLOW_OK;
+            if (async) { // the reduction of the witness words waits until somebody settles the check (settle_pending)
+                c->epsPtr = c->dEps;
+                c->epsStride = 1;
+                return HSFLOW_OK;
+            }
+            return eps_collect_enqueue(c, slots, n_launch - 1, plan_eps_stride(kernel, plan),
+                                       plan_eps_stride(kernel, last_chunk != T ? tailp : plan));
         };
         if (p.use_graph && !p.profile) {
             GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
@@ -390,6 +392,8 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             c->pend.active = true;
             c->pend.params = p;
             c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
+            c->pend.stride = stride; c->pend.n_first = n_launch - 1; c->pend.cnt_first = plan_eps_stride(kernel, plan);
+            c->pend.cnt_last = plan_eps_stride(kernel, last_chunk != T ? tailp : plan);
             c->info.iterations_done = iters;
             c->info.jacobi_launches = launches;
             return HSFLOW_OK;

@@ -142,8 +142,6 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
         HS_TRY(hipMalloc((void **)&c->dV[i], px * sizeof(float)));
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
-    HS_TRY(hipMalloc((void **)&c->dEpsCounter, sizeof(unsigned)));
-    HS_TRY(hipMemset(c->dEpsCounter, 0, sizeof(unsigned)));
     c->epsPtr = c->dEps;
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     // deterministic contents for padding columns and the initial flow
@@ -174,7 +172,6 @@ int hsflow_destroy(hsflow_ctx *c)
     for (int i = 0; i < 3; i++) hipFree(c->dE[i]);
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
-    hipFree(c->dEpsCounter);
     hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dStamps);
     hipFree(c->dScratch);
