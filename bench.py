@@ -141,12 +141,12 @@ def run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barri
     for name in ("plain", "overlap"):
         if name == "overlap":
             s = slab.OverlappedSlabSolver(dist, rank, world, S, S, halo,
-                                          lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local_rank, torch_stream=torch.cuda.Stream(device=local_rank)),
+                                          lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, local_rank, torch_stream=torch.cuda.Stream(device=local_rank), first_row=r0),
                                           stage_on_host=stage)
         else:
             ts = torch.cuda.current_stream(local_rank)
             s = slab.SlabSolver(dist, rank, world, S, S, halo,
-                                lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local_rank, stream=ts.cuda_stream), stage_on_host=stage)
+                                lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, local_rank, stream=ts.cuda_stream, first_row=r0), stage_on_host=stage)
         r0, r1 = s.local_frame_rows()
         A, B = gen_rows(synth, S, S, 3, r0, r1 - r0)
         s.set_frames(A, B)

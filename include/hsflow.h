@@ -136,6 +136,11 @@ void hsflow_default_params(hsflow_params *p);
 int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pairs, void *stream,
                   int own_stream);
 int hsflow_destroy(hsflow_ctx *ctx); /* NULL is accepted; idempotent per handle */
+/* Row-slab decomposition: the context holds rows [first_row, first_row + height) of a larger frame.
+ * The Jacobi update adds its four neighbours in an order that depends on the pixel's checkerboard parity
+ * (x + y) & 1 in the FRAME; telling the context where its row 0 sits (only the parity matters) makes a slab
+ * compute bit for bit what the whole-frame solve computes for the same pixels.  Default 0. */
+int hsflow_set_row_origin(hsflow_ctx *ctx, int first_row);
 
 /* --- frames in ---------------------------------------------------------------------------- */
 

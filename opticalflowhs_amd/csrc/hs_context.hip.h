@@ -51,6 +51,7 @@ struct GraphEntry {
 struct hsflow_ctx {
     int device = 0;
     int W = 0, H = 0, N = 0, P = 0;
+    int org = 0;         // frame row of this context's row 0, modulo 2 (hsflow_set_row_origin)
     long long plane = 0; // elements per pair plane
     hipStream_t stream = nullptr;
     bool own_stream = false;

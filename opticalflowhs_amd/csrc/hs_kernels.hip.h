@@ -77,18 +77,22 @@ __device__ __forceinline__ void sweep_coefs(uint32_t c, float ilambda, float &al
 
 // One Jacobi update in the form above.
 //
-// Canonical order of the 4-neighbour sum (every kernel uses it, so all variants agree bit for bit):
-//   even image column:  ((R + (U + D)) + L) * 0.25      odd column:  ((L + (U + D)) + R) * 0.25
-// This is what the packed-fp32 strip kernel computes without any register shuffles, and it is
-// symmetric under the even reflection x -> -1-x (parity and the roles of L and R flip together),
-// which the reflection halo of the strip kernel needs.
-template <int ODD>
-__device__ __forceinline__ void update_cv(float uL, float uR, float uU, float uD, float vL,
+// Canonical order of the 4-neighbour sum (every kernel uses it, so all variants agree bit for bit): the four
+// neighbours are added as two DIAGONAL pairs, chosen by the pixel's checkerboard parity (x + y) & 1:
+//   even pixel:  ((D + R) + (U + L)) * 0.25        odd pixel:  ((D + L) + (U + R)) * 0.25
+// Why pairs: the pair D(y,x) + R(y,x) = u(y+1,x) + u(y,x+1) of an even pixel is also the pair U + L of the pixel
+// (y+1,x+1) -- even as well -- and likewise along the other diagonal for odd pixels, so a kernel that holds whole
+// rows computes ONE such "cross sum" per pixel and row boundary and adds two of them per pixel: 2 additions per
+// pixel and plane instead of 3 (hs_kernels_strip.hip.h).  Why the checkerboard: under the even reflections
+// x -> -1-x and y -> -1-y the parity flips together with the roles of L/R and U/D, so a mirrored pixel forms the
+// same two pair sums as its source -- the reflection halo of the strip kernels stays a reflection bit for bit.
+// par = (x + y) & 1 of the pixel.
+__device__ __forceinline__ void update_cv(int par, float uL, float uR, float uU, float uD, float vL,
                                           float vR, float vU, float vD, float al, float be,
                                           float ga, float &un, float &vn)
 {
-    const float su = ODD ? ((uL + (uU + uD)) + uR) : ((uR + (uU + uD)) + uL);
-    const float sv = ODD ? ((vL + (vU + vD)) + vR) : ((vR + (vU + vD)) + vL);
+    const float su = par ? ((uD + uL) + (uU + uR)) : ((uD + uR) + (uU + uL));
+    const float sv = par ? ((vD + vL) + (vU + vR)) : ((vD + vR) + (vU + vL));
     const float ub = su * 0.25f;
     const float vb = sv * 0.25f;
     const float q = __fmaf_rn(al, ub, __fmaf_rn(be, vb, ga));
@@ -212,8 +216,9 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
                                                        float *__restrict__ u_out,
                                                        float *__restrict__ v_out, int W, int H,
                                                        int P, long long plane, float ilambda,
-                                                       unsigned *__restrict__ eps_out)
+                                                       unsigned *__restrict__ eps_out, int org)
 {
+    // org: frame row of this context's row 0, modulo 2 (row slabs: the checkerboard of update_cv is the whole frame's)
     // ZERO: the incoming flow is identically zero (first sweep of a solve): nothing is read
     // EPS: eps_out[0] receives max |new - old| of this sweep (atomicMax on the float's bit pattern)
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
@@ -248,8 +253,7 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
             // replicate border: the last image column is its own right neighbour
             const bool last = (x0 + k >= W - 1);
             const float uR = last ? wu[k + 1] : wu[k + 2], vR = last ? wv[k + 1] : wv[k + 2];
-            if (k & 1) update_cv<1>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]);
-            else update_cv<0>(wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]);
+            update_cv((k + y + org) & 1, wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]); // x0 % 4 == 0
             if (EPS && x0 + k < W)
                 e = fmaxf(e, fmaxf(fabsf(wu[k + 1] - nu[k]), fabsf(wv[k + 1] - nv[k])));
         }
@@ -276,10 +280,11 @@ struct FusedGeom {
     int G;                  // RW4 * RH
     int tiles_x, tiles_y;
     int zero_in;            // incoming flow is identically zero: do not read u_in / v_in
+    int org;                // frame row of this context's row 0, modulo 2 (checkerboard phase of update_cv)
 };
 
 enum : unsigned { F_ACTIVE = 1u, F_CORE = 2u, F_GU = 4u, F_GD = 8u, F_GL = 16u, F_GR = 32u };
-// bits [9:8] of the flag word: position pr of image column W-1 inside the group (valid with F_GR)
+// bits [9:8] of the flag word: position pr of image column W-1 inside the group (valid with F_GR); bit 10: y & 1
 
 // GFX9 DPP whole-wavefront shifts by one lane (no LDS traffic): lane l receives lane l-1 / l+1.
 // bound_ctrl with a zero `old` lets the compiler fold the shift into the consuming VALU instruction.
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                 if (x0 == 0) f |= F_GL;
                 const int pr = g.W - 1 - x0;
                 if (pr <= 3) f |= F_GR | ((unsigned)pr << 8);
+                f |= (unsigned)((y + g.org) & 1) << 10;
                 fl[k] = f;
                 const uint4 cw = *(const uint4 *)(coef + base + go[k]);
                 const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
@@ -401,10 +407,11 @@ __global__ __launch_bounds__(NT) void k_jacobi_fused(const uint32_t *__restrict_
                 if (f & F_GL) { uL = cu[k].x; vL = cv[k].x; }        // replicate: column 0 is its own left
                 if (pr == 3) { uR = cu[k].w; vR = cv[k].w; }          // replicate: column W-1 is its own right
                 float nu[4], nv[4];
-                update_cv<0>(uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cAl[k][0], cBe[k][0], cGa[k][0], nu[0], nv[0]);
-                update_cv<1>(cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cAl[k][1], cBe[k][1], cGa[k][1], nu[1], nv[1]);
-                update_cv<0>(cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cAl[k][2], cBe[k][2], cGa[k][2], nu[2], nv[2]);
-                update_cv<1>(cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cAl[k][3], cBe[k][3], cGa[k][3], nu[3], nv[3]);
+                const int py = (int)((f >> 10) & 1u); // parity of the group's image row (x0 % 4 == 0)
+                update_cv(py, uL, cu[k].y, uu.x, ud.x, vL, cv[k].y, vu.x, vd.x, cAl[k][0], cBe[k][0], cGa[k][0], nu[0], nv[0]);
+                update_cv(py ^ 1, cu[k].x, cu[k].z, uu.y, ud.y, cv[k].x, cv[k].z, vu.y, vd.y, cAl[k][1], cBe[k][1], cGa[k][1], nu[1], nv[1]);
+                update_cv(py, cu[k].y, cu[k].w, uu.z, ud.z, cv[k].y, cv[k].w, vu.z, vd.z, cAl[k][2], cBe[k][2], cGa[k][2], nu[2], nv[2]);
+                update_cv(py ^ 1, cu[k].z, uR, uu.w, ud.w, cv[k].z, vR, vu.w, vd.w, cAl[k][3], cBe[k][3], cGa[k][3], nu[3], nv[3]);
                 if (EPS && (f & F_CORE)) { // columns > pr lie outside the image
                     e = fmaxf(e, fmaxf(fabsf(cu[k].x - nu[0]), fabsf(cv[k].x - nv[0])));
                     if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(cu[k].y - nu[1]), fabsf(cv[k].y - nv[1])));

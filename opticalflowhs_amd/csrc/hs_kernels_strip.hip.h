@@ -22,11 +22,12 @@
 #define HS_UNROLL2 0
 #endif
 #ifndef HS_PEEL_LAST_STRIP
-#define HS_PEEL_LAST_STRIP 0
+#define HS_PEEL_LAST_STRIP 1
 #endif
 #ifndef HS_PEEL_LAST_FOLD
 #define HS_PEEL_LAST_FOLD 1
 #endif
+
 
 namespace hsk {
 
@@ -59,6 +60,7 @@ struct StripGeom {
     int NW;             // wavefronts per workgroup
     int tiles_x, tiles_y;
     int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
+    int org;            // frame row of this context's row 0, modulo 2 (row slabs; checkerboard phase of update_cv)
 };
 
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
@@ -88,41 +90,57 @@ __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, 
 #define HS_DIFF1(o, n) ((o) - (n))
 #endif
 
-// One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs, so that every
-// arithmetic step except the four side-neighbour additions is a packed (2 pixels per
-// instruction) v_pk_add/mul/fma_f32.  Summation order = the canonical one of update_cv<>:
-//   p0: ((p1 + (U+D)) + left)   p1: ((p0 + (U+D)) + p2)   p2: ((p3 + (U+D)) + p1)   p3: ((p2 + (U+D)) + right)
+// One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs (p0 is an even image column: the
+// region starts at a multiple of 4), so that most arithmetic is packed (2 pixels per v_pk_add/mul/fma_f32).
 struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
 
-__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const f2 upuP, const f2 upuQ,
-                                                 const f2 upvP, const f2 upvQ, const f2 dnuP, const f2 dnuQ,
-                                                 const f2 dnvP, const f2 dnvQ, RowCoef &c)
+// The canonical 4-neighbour sum (update_cv, hs_kernels.hip.h) adds two diagonal pairs chosen by the pixel's
+// checkerboard parity.  Every such pair straddles one row boundary and belongs to two pixels, so it is formed ONCE:
+//   cross sum of the boundary between rows r and r+1, at pixel i of row r:
+//       s_r[i] = x[r+1][i] + x[r][i+1]   (pixel (r,i) even)        s_r[i] = x[r+1][i] + x[r][i-1]   (odd)
+//   neighbour sum of pixel (r,i):  s_r[i] + s_(r-1)[i-1]  (even)   s_r[i] + s_(r-1)[i+1]  (odd)
+// With E = parity of pixel p0 of the upper row: for E = 0 the cross sum pairs each pixel with the other pixel of
+// its register pair (one packed add with swapped halves) and the neighbour sum reaches over the pair boundary (two
+// DPP adds from the adjacent lanes, two plain adds); for E = 1 it is the other way round.  Rows alternate, so a row
+// costs 2 packed + 2 DPP + 2 plain adds per plane where the straightforward sum costs 4 + 2 + 2.
+struct Cross { f2 uP, uQ, vP, vQ; };
+
+// s of the boundary below row `c` (whose side neighbours it uses; `d` is the row underneath), E = parity of c's p0
+template <int E>
+__device__ __forceinline__ void cross_rows(Cross &s, const f2 cuP, const f2 cuQ, const f2 cvP, const f2 cvQ,
+                                           const f2 duP, const f2 duQ, const f2 dvP, const f2 dvQ)
 {
-    // u plane
-    f2 tP = f2_swap(uP) + (upuP + dnuP);
-    f2 tQ = f2_swap(uQ) + (upuQ + dnuQ);
-    tP.x += wave_from_prev_lane(uQ.y);
-    tP.y += uQ.x;
-    tQ.x += uP.y;
-    tQ.y += wave_from_next_lane(uP.x);
+    if (E == 0) {
+        s.uP = duP + f2_swap(cuP); s.uQ = duQ + f2_swap(cuQ);
+        s.vP = dvP + f2_swap(cvP); s.vQ = dvQ + f2_swap(cvQ);
+    } else {
+        s.uP.x = duP.x + wave_from_prev_lane(cuQ.y); s.uP.y = duP.y + cuQ.x;
+        s.uQ.x = duQ.x + cuP.y;                      s.uQ.y = duQ.y + wave_from_next_lane(cuP.x);
+        s.vP.x = dvP.x + wave_from_prev_lane(cvQ.y); s.vP.y = dvP.y + cvQ.x;
+        s.vQ.x = dvQ.x + cvP.y;                      s.vQ.y = dvQ.y + wave_from_next_lane(cvP.x);
+    }
+}
+
+// One row: neighbour sums from the cross sums below (sc) and above (sp) it, then the update in place.
+// E = parity of the row's p0.  HS_SCALED: the sums ARE the averages at the next scale (file header).
+template <int E>
+__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const Cross &sc, const Cross &sp, RowCoef &c)
+{
+    f2 tP, tQ, sP, sQ;
+    if (E == 0) {
+        tP.x = sc.uP.x + wave_from_prev_lane(sp.uQ.y); tP.y = sc.uP.y + sp.uQ.x;
+        tQ.x = sc.uQ.x + sp.uP.y;                      tQ.y = sc.uQ.y + wave_from_next_lane(sp.uP.x);
+        sP.x = sc.vP.x + wave_from_prev_lane(sp.vQ.y); sP.y = sc.vP.y + sp.vQ.x;
+        sQ.x = sc.vQ.x + sp.vP.y;                      sQ.y = sc.vQ.y + wave_from_next_lane(sp.vP.x);
+    } else {
+        tP = sc.uP + f2_swap(sp.uP); tQ = sc.uQ + f2_swap(sp.uQ);
+        sP = sc.vP + f2_swap(sp.vP); sQ = sc.vQ + f2_swap(sp.vQ);
+    }
 #if HS_SCALED
-    const f2 ubP = tP, ubQ = tQ; // 4^(k+1) * average
+    const f2 ubP = tP, ubQ = tQ, vbP = sP, vbQ = sQ; // 4^(k+1) * average
 #else
-    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f;
+    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f, vbP = sP * 0.25f, vbQ = sQ * 0.25f;
 #endif
-    // v plane
-    f2 sP = f2_swap(vP) + (upvP + dnvP);
-    f2 sQ = f2_swap(vQ) + (upvQ + dnvQ);
-    sP.x += wave_from_prev_lane(vQ.y);
-    sP.y += vQ.x;
-    sQ.x += vP.y;
-    sQ.y += wave_from_next_lane(vP.x);
-#if HS_SCALED
-    const f2 vbP = sP, vbQ = sQ;
-#else
-    const f2 vbP = sP * 0.25f, vbQ = sQ * 0.25f;
-#endif
-    // update
     const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
     const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
     uP = f2_fma(-c.alP, qP, ubP);
@@ -221,7 +239,7 @@ __device__ __forceinline__ void strip_derive(const uint8_t *__restrict__ fA, con
     }
 }
 
-template <int R, int NTMAX, int EPS, bool DERIV>
+template <int R, int NTMAX, int EPS, int E0, bool DERIV>
 __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in,
@@ -275,6 +293,16 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     const int y0 = by * g.CH - g.T + w * R;
     const long long base = (long long)pair * g.plane;
     const bool xin = (x0 >= 0) && (x0 + 3 < g.W); // the whole group lies inside the image
+    // The sweep code is written for ONE checkerboard phase: pixel p0 of register row 0 must be an "E0" pixel
+    // (x0 % 4 == 0, so that is the parity of the row, counted from the frame's row 0: g.org).  R even: every strip
+    // of the launch starts on a row of the parity of T + org (CH is even), which is the template parameter E0 -- the
+    // host launches the matching kernel.
+    // R odd: strips alternate, E0 = 0 is the only instantiation, and a strip that starts on an odd row keeps its
+    // rows in REVERSE order (register row r = image row y0 + R-1-r): mirrored in y, an odd pixel forms the pair
+    // sums of an even one (update_cv: U and D swap roles), so the same code computes the same bits.  Only the
+    // addressing knows: which image row a register row is, and which exchange slot holds a neighbour's edge row.
+    const bool rev = (R & 1) != 0 && ((y0 + g.org) & 1) != 0; // wave-uniform
+    auto img_row = [&](int r) { return rev ? R - 1 - r : r; }; // row of the strip that register row r holds
 
     f2 uP[R], uQ[R], vP[R], vQ[R];
     RowCoef cf[R];
@@ -287,7 +315,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     if (!xedge) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const long long off = base + (long long)mirror_index(y0 + r, g.H) * g.P + x0;
+            const long long off = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P + x0;
             lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!g.zero_in) {
                 lu[r] = *(const float4 *)(u_in + off);
@@ -298,7 +326,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     } else {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const long long row = base + (long long)mirror_index(y0 + r, g.H) * g.P;
+            const long long row = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P;
             // A group that lies completely outside the image on the left mirrors onto an aligned
             // group read backwards (columns -1-k <-> k); the same holds on the right when W % 4 == 0.
             // Those lanes keep the 16-byte loads (from the mirrored address, components reversed).
@@ -339,7 +367,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             lu[r] = a; lv[r] = b; lc[r] = c;
         }
     }
-    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, y0, 1, xin, lc);
+    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, rev ? y0 + R - 1 : y0, rev ? -1 : 1, xin, lc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const float4 lu_ = lu[r], lv_ = lv[r];
@@ -359,7 +387,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     int rdist[R]; // distance of each row from the core rows (0 inside): wave-uniform
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int j = w * R + r, y = y0 + r;
+        const int j = w * R + img_row(r), y = y0 + img_row(r);
         if (j >= g.T && j < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
         rdist[r] = j < g.T ? g.T - j : (j >= g.T + g.CH ? j - (g.T + g.CH - 1) : 0);
     }
@@ -368,46 +396,42 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
 #pragma unroll
         for (int r = 0; r < R; r++)
-            if ((rowcore >> r) & 1u) *(uint4 *)(coef_w + base + (long long)(y0 + r) * g.P + x0) = lc[r];
+            if ((rowcore >> r) & 1u) *(uint4 *)(coef_w + base + (long long)(y0 + img_row(r)) * g.P + x0) = lc[r];
     }
 
-    // One row update.  up*/dn* are OLD neighbour rows; the new row replaces uP[r].. in place.
-    // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later
-    // sweeps skip it (wave-uniform branch), which trims the redundant halo work by about half.
-#ifdef HS_DIAG_NO_COMPUTE /* diagnostic build only: wrong results, times the exchange alone */
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF) do { uP[r] += UUP + DUP; } while (0)
-#else
-#define HS_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF)                                      \
+    // One row: neighbour sums from the cross sums of its two boundaries (sc below, sp above), update in place.
+    // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later sweeps skip it
+    // (wave-uniform branch), which trims the redundant halo work by about half.  PE = parity of the row's pixel p0.
+#define HS_ROW(r, PE, SC, SP)                                                                      \
     do {                                                                                           \
-        if (rdist[r] <= g.T - 1 - s) {                                                             \
-            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
-            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, CF);    \
-            if (EM) {                                                                              \
+        if (rdist[r] <= last) {                                                                    \
+            f2 ouP, ouQ, ovP, ovQ;                                                                 \
+            if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
+            strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                       \
+            if (EM == 1) {                                                                         \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
-                    if (EM == 1) {                                                                 \
-                        const f2 dUP = HS_DIFF(ouP, uP[r]), dUQ = HS_DIFF(ouQ, uQ[r]), dVP = HS_DIFF(ovP, vP[r]), dVQ = HS_DIFF(ovQ, vQ[r]); \
-                        if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
-                            e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dUQ.x)), fabsf(dUQ.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                       \
-                            e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                       \
-                        } else {                                                                   \
-                            e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                       \
-                            if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));          \
-                            if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));          \
-                            if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));          \
-                        }                                                                          \
+                    const f2 dUP = HS_DIFF(ouP, uP[r]), dUQ = HS_DIFF(ouQ, uQ[r]), dVP = HS_DIFF(ovP, vP[r]), dVQ = HS_DIFF(ovQ, vQ[r]); \
+                    if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
+                        e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                           \
+                        e = fmaxf(fmaxf(e, fabsf(dUQ.x)), fabsf(dUQ.y));                           \
+                        e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                           \
+                        e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                           \
+                    } else {                                                                       \
+                        e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                           \
+                        if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));              \
+                        if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));              \
+                        if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));              \
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
-        /* (no scheduling barrier between rows: letting the scheduler overlap them is 1.7 % faster    \
-           and, with this compiler, also spills less in the Eps variants) */                      \
     } while (0)
-#endif
-#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS) /* diagnostic builds only: wrong results */
-#define HS_PUBLISH(buf) do { } while (0)
-#else
+    // cross sums of the boundary below register row A (row B underneath), needed while either row is still swept
+#define HS_CROSS(S, PE, A, B)                                                                      \
+    do {                                                                                           \
+        if (rdist[A] <= last || rdist[B] <= last)                                                  \
+            cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);             \
+    } while (0)
 #define HS_PUBLISH(buf)                                                                            \
     do {                                                                                           \
         float4 *exw = ex + ((size_t)((buf) * NW + w) * 4) * 64 + lane;                             \
@@ -416,91 +440,86 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         exw[128] = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y);                \
         exw[192] = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);                \
     } while (0)
-#endif
 
-#define HS_RAISE(n)                                                                                \
-    do {                                                                                           \
-        if (P2P) {                                                                                 \
-            asm volatile("" ::: "memory"); /* the rows first (LDS keeps a wavefront's order) */    \
-            if (lane == 0) flags[w] = (unsigned)(n);                                               \
-        }                                                                                          \
-    } while (0)
-
-    // Exchange slots: ex[buf][wave][0..3][lane] = {first row u, first row v, last row u, last row v}.
+    // Exchange slots: ex[buf][wave][0..3][lane] = {register row 0: u, v; register row R-1: u, v}.
     // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
     // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
     // LDS writes drain while the interior rows are being computed.
     HS_PUBLISH(0);
-    if (P2P && threadIdx.x < NW) flags[threadIdx.x] = 0;
     __syncthreads();
     if (stamps) st1 = __builtin_amdgcn_s_memtime();
-    const int wu = w > 0 ? w - 1 : 0, su = w > 0 ? 2 : 0;          // strip above: its last row
-    const int wd = w < NW - 1 ? w + 1 : w, sd = w < NW - 1 ? 0 : 2; // strip below: its first row
+    // Whose slot is the row above register row 0 (wu, su) and the row below register row R-1 (wd, sd)?  A strip's
+    // bottom image row is its register row R-1 (slot pair 2) unless it is reversed (then row 0: slot pair 0), its
+    // top image row the other one; for odd R the neighbouring strips are reversed exactly when this one is not.
+    // A reversed strip has the strip BELOW it above its register row 0.
     // (at the region edge the strip's own edge row stands in: junk the validity argument tolerates)
+    const bool nrev = (R & 1) != 0 && !rev; // the strips above and below are reversed
+    const int wa = w > 0 ? w - 1 : w, sa = w > 0 ? (nrev ? 0 : 2) : 0;            // image row above this strip
+    const int wb = w < NW - 1 ? w + 1 : w, sb = w < NW - 1 ? (nrev ? 2 : 0) : 2;  // image row below this strip
+    const int wu = rev ? wb : wa, su = rev ? sb : sa;
+    const int wd = rev ? wa : wb, sd = rev ? sa : sb;
     int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
                     // loop-carried flag makes the register allocator spill inside the loop)
     // One sweep.  EM is the Eps mode of THIS sweep: the launch's own (EPS 0, 1, 2), or for EPS == 3 witness
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
-    // loop, so that the loop keeps the registers of the witness kernel.
+    // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
+    // row 0 (image row y0 + image column x0, x0 % 4 == 0): wave-uniform, rows alternate from there.
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
+        const int last = g.T - 1 - s; // rows with rdist <= last are still swept
         // HS_SCALED: this sweep takes the flow from scale 4^s to 4^(s+1)
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
         const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
-#if defined(HS_DIAG_NO_EXCHANGE) || defined(HS_DIAG_NO_LDS)
-        const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = hu4, du4 = hu4, dv4 = hu4;
-#else
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
         const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
-        float4 hu4, hv4, du4, dv4;
-        if (P2P) {
-            // counters first, rows right behind them in the same batch of LDS reads: if the counters
-            // (read earlier) say "published", the rows (read later) are the published ones; otherwise
-            // the batch is simply repeated
-            for (;;) {
-                asm volatile("" ::: "memory");
-                const unsigned fa = flags[wu], fb = flags[wd];
-                hu4 = eu[0]; hv4 = eu[64];   // old row above the strip
-                du4 = ed[0]; dv4 = ed[64];   // old row below the strip
-                if (fa >= (unsigned)s && fb >= (unsigned)s) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } else {
-            hu4 = eu[0]; hv4 = eu[64];
-            du4 = ed[0]; dv4 = ed[64];
-        }
-#endif
+        const float4 hu4 = eu[0], hv4 = eu[64]; // old row above the strip
+        const float4 du4 = ed[0], dv4 = ed[64]; // old row below the strip
         const f2 huP = f2{hu4.x, hu4.y}, huQ = f2{hu4.z, hu4.w}, hvP = f2{hv4.x, hv4.y}, hvQ = f2{hv4.z, hv4.w};
         const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
         float e = 0.f;
+        constexpr int EL = E0 ^ ((R - 1) & 1); // parity of the last register row
+        Cross sA, s0, sK, sL; // above row 0, below row 0, above row R-1, below row R-1
+        // witness: u at column x0 of an edge row that is a core row (register row 0, else R-1), before the sweep
+        const bool wit0 = (rowcore & 1u) != 0;
+        const float w0 = wit0 ? uP[0].x : uP[R - 1].x;
+        // --- first row (the strip's upper edge)
+        if (rdist[0] <= last) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
         if (R == 1) {
-            const float o0 = uP[0].x;
-            HS_ROW(0, huP, huQ, hvP, hvQ, duP, duQ, dvP, dvQ, cf[0]);
-            if (EM == 2 && (rowcore & 1u))
-                seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(o0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
+            if (rdist[0] <= last) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
         } else {
-            constexpr int R1 = R > 1 ? 1 : 0, RM = R > 2 ? R - 2 : 0;
-            const f2 o0uP = uP[0], o0uQ = uQ[0], o0vP = vP[0], o0vQ = vQ[0];                 // old first row
-            const f2 oNuP = uP[R - 1], oNuQ = uQ[R - 1], oNvP = vP[R - 1], oNvQ = vQ[R - 1]; // old last row
-            HS_ROW(0, huP, huQ, hvP, hvQ, uP[R1], uQ[R1], vP[R1], vQ[R1], cf[0]);
-            // witness: did u change by >= eps_thr at column x0 of the strip's first row (a core row) in any lane?
-            // Old and new value are both in registers at this point (the old first row is kept for row 1 anyway).
-            if (EM == 2 && (rowcore & 1u))
-                seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(o0uP.x, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
-            if (R == 2) HS_ROW(R - 1, o0uP, o0uQ, o0vP, o0vQ, duP, duQ, dvP, dvQ, cf[R - 1]);
-            else HS_ROW(R - 1, uP[RM], uQ[RM], vP[RM], vQ[RM], duP, duQ, dvP, dvQ, cf[R - 1]);
-            if (s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
-            f2 puP = o0uP, puQ = o0uQ, pvP = o0vP, pvQ = o0vQ; // old row r-1 while walking the interior rows
+            constexpr int R1 = R > 1 ? 1 : 0;
+            HS_CROSS(s0, E0, 0, R1);
+        }
+        HS_ROW(0, E0, s0, sA);
+        if (R >= 2) {
+            // --- last row (the lower edge), then both edges go to the other wavefronts
+            constexpr int RM = R > 2 ? R - 2 : 0;
+            if (rdist[R - 1] <= last) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+            if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
+            if (R == 2) HS_ROW(R - 1, EL, sL, s0);
+            else HS_ROW(R - 1, EL, sL, sK);
+        }
+        // witness: did u change by >= eps_thr at column x0 of that edge row in any lane?
+        if (EM == 2 && (rowcore & (1u | (1u << (R - 1)))))
+            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(w0, wit0 ? uP[0].x : uP[R - 1].x)) >= thr_s) != 0 ? 1 : 0;
+        if (s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+        // --- interior rows, top to bottom: each needs the cross sum above it (kept) and the one below (new)
+        if (R >= 3) {
+            Cross sp = s0;
 #pragma unroll
             for (int r = 1; r < R - 1; r++) {
-                const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
-                const int rn = r + 1 < R ? r + 1 : r;
-                if (r + 1 == R - 1) HS_ROW(r, puP, puQ, pvP, pvQ, oNuP, oNuQ, oNvP, oNvQ, cf[r]);
-                else HS_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn], cf[r]);
-                puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
+                Cross sc;
+                if (r == R - 2) sc = sK;
+                else {
+                    const int rn = r + 1 < R ? r + 1 : r;
+                    if (r & 1) HS_CROSS(sc, E0 ^ 1, r, rn);
+                    else HS_CROSS(sc, E0, r, rn);
+                }
+                if (r & 1) HS_ROW(r, E0 ^ 1, sc, sp);
+                else HS_ROW(r, E0, sc, sp);
+                sp = sc;
             }
         }
-        if (R == 1 && s + 1 < g.T) { HS_PUBLISH((s + 1) & 1); HS_RAISE(s + 1); }
         if (EM == 1 && EPS == 3) { // the one measured sweep of a witness launch: folded after the loop
             e = wave_max_nonneg(lanecore ? e : 0.f) * unscale;
             if (lane == 0) eps_lds[16 + w] = e;
@@ -514,9 +533,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
             }
         }
-#if !defined(HS_DIAG_NO_EXCHANGE) && !defined(HS_DIAG_NO_BARRIER)
-        if (!P2P && s + 1 < g.T) __syncthreads();
-#endif
+        if (s + 1 < g.T) __syncthreads();
     };
     if constexpr (EPS == 3) {
 #pragma unroll 1
@@ -548,7 +565,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
     if (EPS == 2 || EPS == 3) {
         const int witnessed = EPS == 3 ? g.T - 1 : g.T; // sweeps that ran in witness mode
-        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & 1u)) ? __builtin_inff() : 0.f;
+        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & (1u | (1u << (R - 1))))) ? __builtin_inff() : 0.f;
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
@@ -560,15 +577,15 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         }
     }
 #undef HS_ROW
+#undef HS_CROSS
 #undef HS_PUBLISH
-#undef HS_RAISE
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
 
     if (lanecore) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((rowcore >> r) & 1u) {
-                const long long off = base + (long long)(y0 + r) * g.P + x0;
+                const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
 #if defined(HS_EXP_NT_STORE) /* experiment (slower): non-temporal stores */
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, (v4f *)(u_out + off));
@@ -596,7 +613,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
 }
 
-template <int R, int NTMAX, int EPS>
+template <int R, int NTMAX, int EPS, int E0>
 __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restrict__ coef,
                                                         const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in,
@@ -607,13 +624,13 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip(const uint32_t *__restri
                                                         unsigned long long *__restrict__ stamps,
                                                         const float eps_thr)
 {
-    strip_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+    strip_body<R, NTMAX, EPS, E0, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
                                      nullptr, nullptr, nullptr);
 }
 
 // First launch of a solve with the derivative pass folded in: reads the two frames instead of the packed
 // derivative plane and writes that plane for the launches that follow (and for hsflow_get_derivatives).
-template <int R, int NTMAX, int EPS>
+template <int R, int NTMAX, int EPS, int E0>
 __global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__restrict__ fA,
                                                               const uint8_t *__restrict__ fB,
                                                               uint32_t *__restrict__ coef_w,
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__r
                                                               unsigned long long *__restrict__ stamps,
                                                               const float eps_thr)
 {
-    strip_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+    strip_body<R, NTMAX, EPS, E0, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
                                     fA, fB, coef_w);
 }
 
@@ -652,7 +669,9 @@ __device__ __forceinline__ float lane_xor32(float x, bool lower)
     return __uint_as_float(lower ? r[0] : r[1]);
 }
 
-template <int R, int NTMAX, int EPS, bool DERIV> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
+// E0 = parity of pixel p0 of register row 0 of BOTH halves: yb has the parity of T (CH is even) and the lower half's
+// reversed order turns its rows' parities around (k_jacobi_strip explains the reversal), so one code path serves both.
+template <int R, int NTMAX, int EPS, int E0, bool DERIV> // EPS: 0 none, 1 Eps of every sweep, 2 witness (see k_jacobi_strip)
 __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                                                        const float *__restrict__ u_in,
                                                        const float *__restrict__ v_in,
@@ -763,11 +782,12 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                 *(uint4 *)(coef_w + base + (long long)(yb + (lower ? 2 * R - 1 - r : r)) * g.P + x0) = lc[r];
     }
 
-#define HF_ROW(r, UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ)                                          \
+#define HF_ROW(r, PE, SC, SP)                                                                      \
     do {                                                                                           \
-        if (rdist[r] <= g.T - 1 - s) {                                                             \
-            const f2 ouP = uP[r], ouQ = uQ[r], ovP = vP[r], ovQ = vQ[r];                           \
-            strip_row_update(uP[r], uQ[r], vP[r], vQ[r], UUP, UUQ, UVP, UVQ, DUP, DUQ, DVP, DVQ, cf[r]); \
+        if (rdist[r] <= last) {                                                                    \
+            f2 ouP, ouQ, ovP, ovQ;                                                                 \
+            if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
+            strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                       \
             if (EM == 1) {                                                                         \
                 if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
                     e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.x, uP[r].x)), fabsf(HS_DIFF1(ovP.x, vP[r].x))));           \
@@ -778,6 +798,11 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define HF_CROSS(S, PE, A, B)                                                                      \
+    do {                                                                                           \
+        if (rdist[A] <= last || rdist[B] <= last)                                                  \
+            cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);             \
     } while (0)
     // slot of (buffer, wavefront, half): two planes of 32 float4
 #define HF_SLOT(buf, ww, hh) (ex + ((size_t)(((buf) * NW + (ww)) * 2 + (hh)) * 2) * 32)
@@ -800,6 +825,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     // one sweep in Eps mode EM (k_jacobi_strip explains EPS == 3: witness sweeps, then one measured sweep)
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
+        const int last = g.T - 1 - s; // rows with rdist <= last are still swept
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
         const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
         const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
@@ -811,27 +837,31 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         const f2 ivP = f2{lane_xor32(vP[R - 1].x, lower), lane_xor32(vP[R - 1].y, lower)};
         const f2 ivQ = f2{lane_xor32(vQ[R - 1].x, lower), lane_xor32(vQ[R - 1].y, lower)};
         float e = 0.f;
-        // register row 0 (the published outer edge) first, so that its LDS write drains under the
-        // other rows; then rows 1..R-1 walking towards the inner boundary, keeping one old row
-        f2 puP = uP[0], puQ = uQ[0], pvP = vP[0], pvQ = vQ[0];
-        if (R == 1) {
-            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, iuP, iuQ, ivP, ivQ);
-        } else {
-            constexpr int R1 = R > 1 ? 1 : 0;
-            HF_ROW(0, ouP_, ouQ_, ovP_, ovQ_, uP[R1], uQ[R1], vP[R1], vQ[R1]);
-        }
-        // witness (k_jacobi_strip explains it): old and new value of the published row -- register row 0 of each
-        // half -- at column x0, both in registers here
-        if (EM == 2)
-            seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(puP.x, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
-        if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+        // register rows 0 .. R-1, from the published outer edge towards the inner boundary: each row needs the cross
+        // sums of the boundary above it (kept from the previous row) and below it (new); row 0 goes to the LDS as soon
+        // as it is done, so that the write drains under the other rows
+        const float w0 = uP[0].x; // witness: the published row's u at column x0 before the sweep
+        Cross sp, sc;
+        if (rdist[0] <= last) cross_rows<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
 #pragma unroll
-        for (int r = 1; r < R; r++) {
-            const f2 kuP = uP[r], kuQ = uQ[r], kvP = vP[r], kvQ = vQ[r];
+        for (int r = 0; r < R; r++) {
             const int rn = r + 1 < R ? r + 1 : r;
-            if (r == R - 1) HF_ROW(r, puP, puQ, pvP, pvQ, iuP, iuQ, ivP, ivQ);
-            else HF_ROW(r, puP, puQ, pvP, pvQ, uP[rn], uQ[rn], vP[rn], vQ[rn]);
-            puP = kuP; puQ = kuQ; pvP = kvP; pvQ = kvQ;
+            if (r == R - 1) {
+                if (rdist[r] <= last) {
+                    if (r & 1) cross_rows<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                    else cross_rows<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                }
+            } else if (r & 1) HF_CROSS(sc, E0 ^ 1, r, rn);
+            else HF_CROSS(sc, E0, r, rn);
+            if (r & 1) HF_ROW(r, E0 ^ 1, sc, sp);
+            else HF_ROW(r, E0, sc, sp);
+            if (r == 0) {
+                // witness (k_jacobi_strip explains it): old and new value of the published row at column x0
+                if (EM == 2)
+                    seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
+                if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
+            }
+            sp = sc;
         }
         if (EM == 1 && EPS == 3) {
             e = wave_max(e) * unscale;
@@ -889,6 +919,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         }
     }
 #undef HF_ROW
+#undef HF_CROSS
 #undef HF_PUBLISH
 #undef HF_SLOT
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
@@ -915,7 +946,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     }
 }
 
-template <int R, int NTMAX, int EPS>
+template <int R, int NTMAX, int EPS, int E0>
 __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restrict__ coef,
                                                        const float *__restrict__ u_in,
                                                        const float *__restrict__ v_in,
@@ -926,12 +957,12 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold(const uint32_t *__restric
                                                        unsigned long long *__restrict__ stamps,
                                                        const float eps_thr)
 {
-    fold_body<R, NTMAX, EPS, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+    fold_body<R, NTMAX, EPS, E0, false>(coef, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
                                     nullptr, nullptr, nullptr);
 }
 
 // The folded kernel as the first launch of a solve, derivative pass included (see k_jacobi_strip_deriv).
-template <int R, int NTMAX, int EPS>
+template <int R, int NTMAX, int EPS, int E0>
 __global__ __launch_bounds__(NTMAX) void k_jacobi_fold_deriv(const uint8_t *__restrict__ fA,
                                                              const uint8_t *__restrict__ fB,
                                                              uint32_t *__restrict__ coef_w,
@@ -944,7 +975,7 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_fold_deriv(const uint8_t *__re
                                                              unsigned long long *__restrict__ stamps,
                                                              const float eps_thr)
 {
-    fold_body<R, NTMAX, EPS, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+    fold_body<R, NTMAX, EPS, E0, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
                                    fA, fB, coef_w);
 }
 

@@ -48,7 +48,7 @@ bool make_plan(const hsflow_ctx *c, int T, int tw, int th, int nt, FusedPlan &be
                     g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
                     g.CW = CW; g.CH = CH; g.T = T; g.HX = HX;
                     g.RW4 = RW4; g.RH = RH; g.RS = RS; g.G = (int)G;
-                    g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
+                    g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0; g.org = c->org;
                 }
             }
         }
@@ -192,7 +192,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
                 hsk::StripGeom &g = best.g;
                 g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
                 g.T = T; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
-                g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0;
+                g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0; g.org = c->org;
             }
         }
     }
@@ -218,13 +218,18 @@ int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fol
     return bestT;
 }
 
-template <int R, int NTMAX, int EPS, bool FOLD> // EPS: 0 none, 1 every sweep, 2 witness (strip kernel only)
-hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
-                          float *uo, float *vo, float coeff, bool configure_only)
+// The checkerboard phase the kernel is compiled for (hs_kernels_strip.hip.h): the folded kernel and the strip kernel
+// with an even row count start every strip on a row of the parity of T; odd row counts have one instantiation
+// (strips that start on an odd row keep their rows in reverse order instead).
+int strip_phase(const StripPlan &p) { return (p.fold || (p.R & 1) == 0) ? ((p.g.T + p.g.org) & 1) : 0; }
+
+template <int R, int NTMAX, int EPS, bool FOLD, int E0> // EPS: 0 none, 1 every sweep, 2 witness, 3 witness + last sweep measured
+hipError_t launch_strip_te(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                           float *uo, float *vo, float coeff, bool configure_only)
 {
     auto kern = [] {
-        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS>;
-        else return hsk::k_jacobi_strip<R, NTMAX, EPS>;
+        if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS, E0>;
+        else return hsk::k_jacobi_strip<R, NTMAX, EPS, E0>;
     }();
     static bool configured[64] = {};
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
@@ -237,6 +242,16 @@ hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
                        uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
+}
+
+template <int R, int NTMAX, int EPS, bool FOLD>
+hipError_t launch_strip_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                          float *uo, float *vo, float coeff, bool cfg)
+{
+    if constexpr (FOLD || (R & 1) == 0) {
+        if (strip_phase(p)) return launch_strip_te<R, NTMAX, EPS, FOLD, 1>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return launch_strip_te<R, NTMAX, EPS, FOLD, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
 }
 
 template <int EPS, bool FOLD>
@@ -259,13 +274,13 @@ hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *
 }
 
 // The strip / folded kernel with the derivative pass in its load phase (first launch of a solve).
-template <int R, int NTMAX, int EPS, bool FOLD>
-hipError_t launch_strip_deriv_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
-                                float *uo, float *vo, float coeff, bool configure_only)
+template <int R, int NTMAX, int EPS, bool FOLD, int E0>
+hipError_t launch_strip_deriv_te(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                                 float *uo, float *vo, float coeff, bool configure_only)
 {
     auto kern = [] {
-        if constexpr (FOLD) return hsk::k_jacobi_fold_deriv<R, NTMAX, EPS>;
-        else return hsk::k_jacobi_strip_deriv<R, NTMAX, EPS>;
+        if constexpr (FOLD) return hsk::k_jacobi_fold_deriv<R, NTMAX, EPS, E0>;
+        else return hsk::k_jacobi_strip_deriv<R, NTMAX, EPS, E0>;
     }();
     static bool configured[64] = {};
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
@@ -278,6 +293,16 @@ hipError_t launch_strip_deriv_t(const hsflow_ctx *c, const StripPlan &p, const f
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi,
                        uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
+}
+
+template <int R, int NTMAX, int EPS, bool FOLD>
+hipError_t launch_strip_deriv_t(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
+                                float *uo, float *vo, float coeff, bool cfg)
+{
+    if constexpr (FOLD || (R & 1) == 0) {
+        if (strip_phase(p)) return launch_strip_deriv_te<R, NTMAX, EPS, FOLD, 1>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return launch_strip_deriv_te<R, NTMAX, EPS, FOLD, 0>(c, p, ui, vi, uo, vo, coeff, cfg);
 }
 
 template <int EPS, bool FOLD>
@@ -370,7 +395,7 @@ hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const f
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
 #define HS_SIMPLE(E, Z)                                                                            \
     hipLaunchKernelGGL((hsk::k_jacobi_simple<E, Z>), grid, block, 0, c->stream, c->dCoef, ui, vi, uo, vo, \
-                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr)
+                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr, c->org)
     if (eps) { if (zero_in) HS_SIMPLE(true, true); else HS_SIMPLE(true, false); }
     else { if (zero_in) HS_SIMPLE(false, true); else HS_SIMPLE(false, false); }
 #undef HS_SIMPLE

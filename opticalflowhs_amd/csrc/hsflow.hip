@@ -158,6 +158,20 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     return HSFLOW_OK;
 }
 
+int hsflow_set_row_origin(hsflow_ctx *c, int first_row)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st;
+    const int org = first_row & 1;
+    if (org != c->org) {
+        drop_graphs(c); // captured launches carry the phase (kernel choice and geometry)
+        c->lastl.valid = false;
+        c->org = org;
+    }
+    return HSFLOW_OK;
+}
+
 int hsflow_destroy(hsflow_ctx *c)
 {
     if (!c) return HSFLOW_OK;

@@ -39,6 +39,17 @@ def chunks(total, size):
     return out
 
 
+def _make(make_backend, width, local_height, first_row):
+    """make_backend(width, local_height[, first_row]): the frame row of the slab's row 0 is passed where the
+    factory takes it (the HIP backend needs its parity, see hsflow_set_row_origin)."""
+    import inspect
+    try:
+        n = len(inspect.signature(make_backend).parameters)
+    except (TypeError, ValueError):
+        n = 2
+    return make_backend(width, local_height, first_row) if n >= 3 else make_backend(width, local_height)
+
+
 class HSFlowSlabBackend(object):
     """Per-rank solver over the local rows (product implementation: the HIP context).
 
@@ -49,7 +60,7 @@ class HSFlowSlabBackend(object):
     (`hsflow_solve_async`), the halo copies ride the same stream, and RCCL orders itself against that
     stream -- the host never waits between chunks, so the GPU runs the chunks back to back."""
 
-    def __init__(self, hs, width, local_height, device, stream=None, torch_stream=None):
+    def __init__(self, hs, width, local_height, device, stream=None, torch_stream=None, first_row=0):
         import torch
         self.torch = torch
         self.hs = hs
@@ -59,6 +70,7 @@ class HSFlowSlabBackend(object):
         if torch_stream is not None:
             stream = torch_stream.cuda_stream
         self.ctx = hs.HSFlow(width, local_height, 1, device=device, stream=stream, own_stream=stream is None)
+        self.ctx.set_row_origin(first_row)  # the slab's rows keep the frame's checkerboard phase
         self.width, self.height, self.device = width, local_height, device
         self.enqueue_only = stream is not None
 
@@ -130,7 +142,7 @@ class SlabSolver(object):
         self.lo, self.hi, self.top, self.bot = slab_extent(height, world, rank, halo)
         self.row0 = self.lo - self.top                    # first frame row held locally
         self.local_height = (self.hi + self.bot) - self.row0
-        self.backend = make_backend(width, self.local_height)
+        self.backend = _make(make_backend, width, self.local_height, self.row0)
         self.stage_on_host = stage_on_host
         self._bufs = None
 
@@ -234,7 +246,7 @@ class OverlappedSlabSolver(object):
         for j in range(2):
             lo, hi, top, bot = slab_extent(height, vworld, 2 * rank + j, halo)
             sub = dict(lo=lo, hi=hi, top=top, bot=bot, row0=lo - top, local_height=(hi + bot) - (lo - top))
-            sub["backend"] = make_backend(width, sub["local_height"])
+            sub["backend"] = _make(make_backend, width, sub["local_height"], sub["row0"])
             sub["pending"] = None   # (work handles, wire buffers, device buffers, halo row) of a posted exchange
             sub["bufs"] = None
             self.subs.append(sub)

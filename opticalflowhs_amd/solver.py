@@ -100,6 +100,11 @@ class HSFlow(object):
     def __exit__(self, *a):
         self.close()
 
+    def set_row_origin(self, first_row):
+        """The context holds rows [first_row, first_row + height) of a larger frame (row slabs): keeps the
+        checkerboard phase of the update's summation order that of the whole frame (bit-identical results)."""
+        self._check(self._lib.hsflow_set_row_origin(self._h, int(first_row)))
+
     # -- frames in -----------------------------------------------------------------------
     def set_frames(self, prev, curr, pair=0):
         """u8 single-channel frames: host numpy arrays (H, W) or CUDA tensors (H, W)."""

@@ -515,7 +515,7 @@ def test_c5_strip_500_sweeps_against_oracle_and_slab(hs, oracle, gpu_ok):
 
     def run(rank):
         try:
-            s = slab.SlabSolver(LocalDist(rank), rank, 2, W, H, 16, lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0))
+            s = slab.SlabSolver(LocalDist(rank), rank, 2, W, H, 16, lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, 0, first_row=r0))
             r0, r1 = s.local_frame_rows()
             s.set_frames(A[r0:r1], B[r0:r1])
             n_ex = s.solve(1.0, it)

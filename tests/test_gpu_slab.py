@@ -74,10 +74,10 @@ def test_slab_matches_single_gpu_bit_for_bit(hs, gpu_ok, world, halo, iters, sha
             if overlapped:  # two sub-slabs per rank, each context on its own torch stream, calls only enqueued
                 import torch
                 s = slab.OverlappedSlabSolver(LocalDist(rank), rank, world, W, H, halo,
-                                              lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0, torch_stream=torch.cuda.Stream()))
+                                              lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, 0, torch_stream=torch.cuda.Stream(), first_row=r0))
             else:
                 s = slab.SlabSolver(LocalDist(rank), rank, world, W, H, halo,
-                                    lambda w, h: slab.HSFlowSlabBackend(hs, w, h, 0))
+                                    lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, 0, first_row=r0))
             r0, r1 = s.local_frame_rows()
             s.set_frames(A[r0:r1], B[r0:r1])
             s.solve(0.7, iters)

@@ -50,7 +50,7 @@ def main():
         # two sub-slabs per rank, each context on its own torch stream: the RCCL exchange of one sub-slab is
         # in flight while the other one is swept
         s = slab.OverlappedSlabSolver(dist, rank, world, W, H, args.halo,
-                                      lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, torch_stream=torch.cuda.Stream(device=local)),
+                                      lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, local, torch_stream=torch.cuda.Stream(device=local), first_row=r0),
                                       stage_on_host=(backend != "nccl"))
     else:
         # the context shares torch's current stream: sweeps, halo copies and RCCL are ordered on the device,
@@ -58,7 +58,7 @@ def main():
         tstream = torch.cuda.Stream(device=local)
         torch.cuda.set_stream(tstream)
         s = slab.SlabSolver(dist, rank, world, W, H, args.halo,
-                            lambda w, h: slab.HSFlowSlabBackend(hs, w, h, local, stream=tstream.cuda_stream),
+                            lambda w, h, r0: slab.HSFlowSlabBackend(hs, w, h, local, stream=tstream.cuda_stream, first_row=r0),
                             stage_on_host=(backend != "nccl"))
     r0, r1 = s.local_frame_rows()
     A, B = synth.translating_pair(W, H, seed=3, row0=r0, rows=r1 - r0)  # each rank generates only its rows

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Instruction mix of the sweep loop of the strip / fold kernels, from a device assembly file (hipcc -S --cuda-device-only).
-usage: tools/isa_loop.py file.s [substring of the mangled kernel name ...]
-The sweep loop is taken to be the smallest loop that holds >= 20 v_pk_fma_f32."""
+"""Instruction mix of the sweep loop of the strip / fold kernels, from a device assembly file
+(hipcc -S --cuda-device-only ...).   usage: tools/isa_loop.py file.s [substring of the mangled kernel name ...] [--dump]
+The sweep loop = the strongly connected component of the kernel's control-flow graph that holds the most
+v_pk_fma_f32 (every block counted once, i.e. all rows active).  The issue estimate prices packed and DPP
+instructions at 4.2 cycles and the other VALU instructions at 2.3 (profiles/r01_ubench_valu.txt)."""
 import re
 import sys
 from collections import Counter
+
+sys.setrecursionlimit(100000)
 
 
 def functions(lines):
@@ -19,20 +23,63 @@ def functions(lines):
     return out
 
 
-def sweep_loop(f):
-    labels = {}
-    for i, l in enumerate(f):
+def blocks(f):
+    """[(label, [instructions])] in layout order; successors by label."""
+    bl, cur, name = [], [], 'entry'
+    for l in f[1:]:
         m = re.match(r'^(\.LBB\d+_\d+):', l)
+        t = l.strip()
         if m:
-            labels[m.group(1)] = i
-    best = None
-    for i, l in enumerate(f):
-        m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            body = [x.strip() for x in f[labels[m.group(1)]:i + 1] if x.strip() and not x.strip().startswith((';', '.'))]
-            if sum(1 for x in body if x.startswith('v_pk_fma')) >= 20 and (best is None or len(body) < len(best)):
-                best = body
-    return best
+            bl.append((name, cur))
+            name, cur = m.group(1), []
+        elif t and not t.startswith((';', '.')):
+            cur.append(t)
+    bl.append((name, cur))
+    succ = {}
+    for i, (n, ins) in enumerate(bl):
+        s = []
+        fall = True
+        for x in ins:
+            m = re.match(r's_(c?)branch\w*\s+(\.LBB\d+_\d+)', x)
+            if m:
+                s.append(m.group(2))
+                if not m.group(1):
+                    fall = False
+            if x.startswith('s_endpgm'):
+                fall = False
+        if fall and i + 1 < len(bl):
+            s.append(bl[i + 1][0])
+        succ[n] = s
+    return bl, succ
+
+
+def sccs(nodes, succ):
+    index, low, on, st, out, c = {}, {}, set(), [], [], [0]
+
+    def go(v):
+        index[v] = low[v] = c[0]
+        c[0] += 1
+        st.append(v)
+        on.add(v)
+        for w in succ.get(v, []):
+            if w not in index:
+                go(w)
+                low[v] = min(low[v], low[w])
+            elif w in on:
+                low[v] = min(low[v], index[w])
+        if low[v] == index[v]:
+            comp = []
+            while True:
+                w = st.pop()
+                on.discard(w)
+                comp.append(w)
+                if w == v:
+                    break
+            out.append(comp)
+    for v in nodes:
+        if v not in index:
+            go(v)
+    return out
 
 
 def classify(body):
@@ -64,18 +111,30 @@ def classify(body):
 
 def main():
     lines = open(sys.argv[1]).read().split('\n')
-    pats = sys.argv[2:]
+    pats = [a for a in sys.argv[2:] if not a.startswith('--')]
     for name, f in functions(lines).items():
         if pats and not any(p in name for p in pats):
             continue
-        body = sweep_loop(f)
-        if not body:
+        bl, succ = blocks(f)
+        ins = dict(bl)
+        best, bestn = None, 0
+        for comp in sccs([n for n, _ in bl], succ):
+            if len(comp) == 1 and comp[0] not in succ.get(comp[0], []):
+                continue
+            n = sum(1 for b in comp for x in ins[b] if x.startswith('v_pk_fma'))
+            if n > bestn:
+                best, bestn = comp, n
+        if not best:
             continue
+        order = [n for n, _ in bl if n in set(best)]
+        body = [x for n in order for x in ins[n]]
         c = classify(body)
-        valu_cycles = 4.2 * (c['v_pk'] + c['dpp']) + 2.3 * (c['v_mov'] + c['v_other'])
-        print('%s\n  loop: %d instr, issue estimate %.0f cycles per wavefront-sweep  %s' % (name, len(body), valu_cycles, dict(sorted(c.items()))))
+        est = 4.2 * (c['v_pk'] + c['dpp']) + 2.3 * (c['v_mov'] + c['v_other'])
+        print('%s\n  loop: %d blocks, %d instr, VALU issue estimate %.0f cycles per wavefront-sweep  %s' % (name, len(best), len(body), est, dict(sorted(c.items()))))
         if '--dump' in sys.argv:
-            print('\n'.join(body))
+            for n in order:
+                print(n + ':')
+                print('\n'.join('    ' + x for x in ins[n]))
 
 
 if __name__ == '__main__':
