@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--iter-only", action="store_true", help="headline with ITER termination instead of the reference's ITER|EPS")
+    ap.add_argument("--no-side", action="store_true", help="skip the timing of the other termination form (profiling runs)")
     ap.add_argument("--sync-solves", action="store_true", help="hsflow_solve (host waits for every solve) instead of hsflow_solve_async")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the single-thread cpu_baseline sample")
@@ -284,11 +285,13 @@ def main():
     # spread: the same block again, --blocks - 1 more times
     block_ms = [elapsed / args.steps * 1e3] + [timed_block(step) / args.steps * 1e3 for _ in range(max(0, args.blocks - 1))]
     # the other termination form beside it (same steps, same block structure)
-    step2 = stepper(side_p)
-    for _ in range(min(args.warmup, 5)):
-        step2()
-    side_ms = [timed_block(step2) / args.steps * 1e3 for _ in range(max(1, min(args.blocks, 3)))]
-    info2 = ctx.info()
+    side_ms, info2 = [float("nan")], info
+    if not args.no_side:
+        step2 = stepper(side_p)
+        for _ in range(min(args.warmup, 5)):
+            step2()
+        side_ms = [timed_block(step2) / args.steps * 1e3 for _ in range(max(1, min(args.blocks, 3)))]
+        info2 = ctx.info()
 
     # Per-kernel durations with HIP events on the launch stream: eager launches of the same solve bracketed by
     # hipEventRecord inside the C ABI (params.profile).  Events between graph nodes would perturb the timed

@@ -27,6 +27,13 @@
 #ifndef HS_PEEL_LAST_FOLD
 #define HS_PEEL_LAST_FOLD 1
 #endif
+#ifndef HS_UNGATED_CORE
+#define HS_UNGATED_CORE 0 /* experiment, rejected: two copies of the sweep body make the register allocator spill 66 registers */
+#endif
+#ifndef HS_DIAG /* bit mask of diagnostic knobs in the strip sweep (timing experiments only, results are wrong): 1 no LDS
+                   exchange, 2 no barrier, 4 no trapezoid gating, 8 no arithmetic */
+#define HS_DIAG 0
+#endif
 
 
 namespace hsk {
@@ -391,6 +398,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (j >= g.T && j < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
         rdist[r] = j < g.T ? g.T - j : (j >= g.T + g.CH ? j - (g.T + g.CH - 1) : 0);
     }
+    bool allcore = true; // every row of this wavefront is swept in every sweep (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < R; r++) allcore = allcore && rdist[r] == 0;
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
     if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
@@ -402,12 +412,14 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // One row: neighbour sums from the cross sums of its two boundaries (sc below, sp above), update in place.
     // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later sweeps skip it
     // (wave-uniform branch), which trims the redundant halo work by about half.  PE = parity of the row's pixel p0.
+#define HS_ACT(r) (!GATED || rdist[r] <= last)
 #define HS_ROW(r, PE, SC, SP)                                                                      \
     do {                                                                                           \
-        if (rdist[r] <= last) {                                                                    \
+        if (HS_ACT(r)) {                                                                           \
             f2 ouP, ouQ, ovP, ovQ;                                                                 \
             if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
-            strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                       \
+            if (HS_DIAG & 8) uP[r] += SC.uP + SP.uP;                                               \
+            else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
             if (EM == 1) {                                                                         \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
                     const f2 dUP = HS_DIFF(ouP, uP[r]), dUQ = HS_DIFF(ouQ, uQ[r]), dVP = HS_DIFF(ovP, vP[r]), dVQ = HS_DIFF(ovQ, vQ[r]); \
@@ -425,12 +437,17 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
+        /* straight-line form: keep the rows apart, or the scheduler overlaps them all and spills */ \
+        if (!GATED) __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
     // cross sums of the boundary below register row A (row B underneath), needed while either row is still swept
 #define HS_CROSS(S, PE, A, B)                                                                      \
     do {                                                                                           \
-        if (rdist[A] <= last || rdist[B] <= last)                                                  \
-            cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);             \
+        if (HS_ACT(A) || HS_ACT(B)) {                                                              \
+            if (HS_DIAG & 8) S.uP = uP[A] + uP[B];                                                 \
+            else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
+        }                                                                                          \
+        if (!GATED) __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
 #define HS_PUBLISH(buf)                                                                            \
     do {                                                                                           \
@@ -464,45 +481,61 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
     // row 0 (image row y0 + image column x0, x0 % 4 == 0): wave-uniform, rows alternate from there.
-    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
+    // GATED = false: the straight-line form for wavefronts whose rows are all core rows (never skipped): no compare and
+    // branch per row and per boundary -- these wavefronts are the ones every sweep waits for.
+    auto sweep_g = [&](const int s, auto em_tag, auto gated_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
+        constexpr bool GATED = decltype(gated_tag)::value;
+#if HS_DIAG & 4 /* diagnostic build: every row swept in every sweep (no trapezoid) */
+        const int last = 1 << 20;
+#else
         const int last = g.T - 1 - s; // rows with rdist <= last are still swept
+#endif
         // HS_SCALED: this sweep takes the flow from scale 4^s to 4^(s+1)
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
-        const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
+        // (wave-uniform: kept in a scalar register, the sweep loop has no vector register to spare)
+        const float thr_s = HS_SCALED ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_ldexpf(eps_thr, 2 * (s + 1))))) : eps_thr;
+#if HS_DIAG & 1 /* diagnostic build (wrong results): no LDS traffic, the strip's own edge rows stand in */
+        const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);
+        const float4 du4 = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y), dv4 = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);
+#else
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
         const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
         const float4 hu4 = eu[0], hv4 = eu[64]; // old row above the strip
         const float4 du4 = ed[0], dv4 = ed[64]; // old row below the strip
+#endif
         const f2 huP = f2{hu4.x, hu4.y}, huQ = f2{hu4.z, hu4.w}, hvP = f2{hv4.x, hv4.y}, hvQ = f2{hv4.z, hv4.w};
         const f2 duP = f2{du4.x, du4.y}, duQ = f2{du4.z, du4.w}, dvP = f2{dv4.x, dv4.y}, dvQ = f2{dv4.z, dv4.w};
         float e = 0.f;
         constexpr int EL = E0 ^ ((R - 1) & 1); // parity of the last register row
         Cross sA, s0, sK, sL; // above row 0, below row 0, above row R-1, below row R-1
-        // witness: u at column x0 of an edge row that is a core row (register row 0, else R-1), before the sweep
-        const bool wit0 = (rowcore & 1u) != 0;
-        const float w0 = wit0 ? uP[0].x : uP[R - 1].x;
+        const float w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
         // --- first row (the strip's upper edge)
-        if (rdist[0] <= last) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
+        if (HS_ACT(0)) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
+        if (!GATED) __builtin_amdgcn_sched_barrier(0);
         if (R == 1) {
-            if (rdist[0] <= last) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
+            if (HS_ACT(0)) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
         } else {
             constexpr int R1 = R > 1 ? 1 : 0;
             HS_CROSS(s0, E0, 0, R1);
         }
         HS_ROW(0, E0, s0, sA);
+        // witness: did u change by >= eps_thr at column x0 of register row 0 (where that is a core row) in any lane?
+        // (The host runs witness launches only with plans in which some wavefront has such a row: strip_has_witness.)
+        if (EM == 2 && (rowcore & 1u))
+            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
         if (R >= 2) {
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
-            if (rdist[R - 1] <= last) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+            if (HS_ACT(R - 1)) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+            if (!GATED) __builtin_amdgcn_sched_barrier(0);
             if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
             if (R == 2) HS_ROW(R - 1, EL, sL, s0);
             else HS_ROW(R - 1, EL, sL, sK);
         }
-        // witness: did u change by >= eps_thr at column x0 of that edge row in any lane?
-        if (EM == 2 && (rowcore & (1u | (1u << (R - 1)))))
-            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(w0, wit0 ? uP[0].x : uP[R - 1].x)) >= thr_s) != 0 ? 1 : 0;
+#if !(HS_DIAG & 1)
         if (s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+#endif
         // --- interior rows, top to bottom: each needs the cross sum above it (kept) and the one below (new)
         if (R >= 3) {
             Cross sp = s0;
@@ -533,7 +566,16 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 if (lane == 0) eps_out[(size_t)(s - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
             }
         }
+#if !(HS_DIAG & 2) /* diagnostic build: no barrier */
         if (s + 1 < g.T) __syncthreads();
+#endif
+    };
+    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
+#if HS_UNGATED_CORE
+        if (allcore) sweep_g(s, em_tag, std::false_type{});
+        else
+#endif
+            sweep_g(s, em_tag, std::true_type{});
     };
     if constexpr (EPS == 3) {
 #pragma unroll 1
@@ -565,7 +607,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
     if (EPS == 2 || EPS == 3) {
         const int witnessed = EPS == 3 ? g.T - 1 : g.T; // sweeps that ran in witness mode
-        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & (1u | (1u << (R - 1))))) ? __builtin_inff() : 0.f;
+        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & 1u)) ? __builtin_inff() : 0.f;
         __syncthreads();
         if (w == 0) {
             const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
@@ -577,6 +619,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         }
     }
 #undef HS_ROW
+#undef HS_ACT
 #undef HS_CROSS
 #undef HS_PUBLISH
     if (stamps) st2 = __builtin_amdgcn_s_memtime();

@@ -258,6 +258,14 @@ template <int EPS, bool FOLD>
 hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                           float *uo, float *vo, float coeff, bool cfg)
 {
+#ifdef HS_DIAG_MIN /* diagnostic builds (tools/diag_build.sh): the R = 4 / 5 / 6 strip kernels without Eps only */
+    if constexpr (!FOLD && EPS == 0) {
+        if (p.R == 4) return launch_strip_t<4, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+        if (p.R == 5) return launch_strip_t<5, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+        if (p.R == 6) return launch_strip_t<6, 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
+    }
+    return hipErrorInvalidConfiguration;
+#else
     switch (p.R) {
     case 1: return launch_strip_t<1, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 2: return launch_strip_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
@@ -271,6 +279,7 @@ hipError_t launch_strip_e(const hsflow_ctx *c, const StripPlan &p, const float *
     case 8: return launch_strip_t<8, 512, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     }
     return hipErrorInvalidConfiguration;
+#endif
 }
 
 // The strip / folded kernel with the derivative pass in its load phase (first launch of a solve).
@@ -309,6 +318,9 @@ template <int EPS, bool FOLD>
 hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const float *ui, const float *vi,
                                 float *uo, float *vo, float coeff, bool cfg)
 {
+#ifdef HS_DIAG_MIN
+    return hipErrorInvalidConfiguration;
+#else
     switch (p.R) { // the same thread limits as launch_strip_e
     case 1: return launch_strip_deriv_t<1, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     case 2: return launch_strip_deriv_t<2, 1024, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
@@ -320,6 +332,7 @@ hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const f
     case 6: return launch_strip_deriv_t<6, FOLD ? 512 : 768, EPS, FOLD>(c, p, ui, vi, uo, vo, coeff, cfg);
     }
     return hipErrorInvalidConfiguration;
+#endif
 }
 
 // Can the first launch of a solve compute the derivatives itself (k_jacobi_strip_deriv / k_jacobi_fold_deriv)?
@@ -327,11 +340,39 @@ hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const f
 // region (256 or 128 columns x all its rows).
 bool strip_deriv_fusable(const hsflow_ctx *c, const JPlan &pl)
 {
+#ifdef HS_DIAG_MIN
+    return false;
+#endif
     static const bool off = getenv("HSFLOW_NO_DERIV_FUSION") != nullptr;
     if (off || (pl.kind != HSFLOW_KERNEL_STRIP && pl.kind != HSFLOW_KERNEL_FOLD)) return false;
     if (pl.s.R < 1 || pl.s.R > 6) return false; // 7 and 8 rows per lane: not instantiated
     const int region_w = pl.s.fold ? 128 : 256, region_h = pl.s.g.NW * pl.s.R * (pl.s.fold ? 2 : 1);
     return c->W >= region_w && c->H >= region_h;
+}
+
+// Can a witness launch of this plan prove anything?  The kernels watch register row 0 of a wavefront (of either half
+// in the folded kernel), which must be a core row of the tile.  With an odd row count the strips alternate between
+// normal and reversed row order (hs_kernels_strip.hip.h), starting with either, depending on the tile row.
+bool strip_has_witness(const JPlan &pl)
+{
+    if (pl.kind != HSFLOW_KERNEL_STRIP && pl.kind != HSFLOW_KERNEL_FOLD) return false;
+    const hsk::StripGeom &g = pl.s.g;
+    const int R = pl.s.R;
+    auto core = [&](int j) { return j >= g.T && j < g.T + g.CH; };
+    if (pl.s.fold) {
+        for (int w = 0; w < g.NW; w++)
+            if (core(w * 2 * R) || core(w * 2 * R + 2 * R - 1)) return true;
+        return false;
+    }
+    for (int first_rev = 0; first_rev < ((R & 1) ? 2 : 1); first_rev++) {
+        bool any = false;
+        for (int w = 0; w < g.NW && !any; w++) {
+            const bool rev = (R & 1) && (((w & 1) != 0) != (first_rev != 0));
+            any = core(w * R + (rev ? R - 1 : 0));
+        }
+        if (!any) return false;
+    }
+    return true;
 }
 
 bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)

@@ -269,7 +269,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
     const long long budget = S.budget;
     const int iters = (int)budget;
     const size_t px = (size_t)c->plane * c->N;
-    const bool witness = (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact;
+    bool witness = (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact && strip_has_witness(plan);
     const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
     if (p.use_previous) { // the starting flow is kept: the ping-pong buffers get overwritten
         if (!c->dUb) HS_HIP(c, hipMalloc((void **)&c->dUb, px * sizeof(float)));
@@ -288,7 +288,12 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
     if (has_tail) {
         if (!make_jplan(c, kernel, iters % T, p, tailp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
         stride = std::max(stride, plan_eps_stride(kernel, tailp));
+        // (a tail of one sweep is measured, not witnessed: the synchronous pass's mode 3; an asynchronous pass needs it able)
+        if (witness && (async || iters % T > 1) && !strip_has_witness(tailp)) witness = false;
     }
+    if (async && !witness)
+        return fail(c, HSFLOW_E_ARG, "solve_async with ITER|EPS: this launch plan (core tile thinner than a strip) cannot run witness launches; "
+                                     "use hsflow_solve or other tuning parameters");
     int launches = 0;
     if (witness) {
         // Witness pass: all launches but the last run k_jacobi_strip<.., 2>, which costs almost

@@ -174,7 +174,10 @@ def test_derivative_pass_fused_into_first_launch(hs, oracle, gpu_ok):
                         rows = (i1["threads"] // 64) * i1["groups_per_thread"] * (2 if fold else 1)
                         fusable = i1["kernel"] in (hs.KERNEL_STRIP, hs.KERNEL_FOLD) and \
                             W >= (128 if fold else 256) and H >= rows and i1["groups_per_thread"] <= 6
-                        assert i1["deriv_fused"] == (1 if fusable else 0), (W, H, it, R, tt, prev, i1)
+                        if tt == ITER:
+                            assert i1["deriv_fused"] == (1 if fusable else 0), (W, H, it, R, tt, prev, i1)
+                        else:  # ITER|EPS: plans whose strips have no core row at an edge run the exact pass (separate kernel)
+                            assert i1["deriv_fused"] in ((0, 1) if fusable else (0,)), (W, H, it, R, tt, prev, i1)
                         assert np.array_equal(dx, Ix) and np.array_equal(dy, Iy) and np.array_equal(dt, It), (W, H, it, R, tt, prev)
                         if prev:
                             ctx.solve(lam=2.0, max_iter=3, term_type=ITER, kernel=hs.KERNEL_SIMPLE)
