@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define HSFLOW_VERSION_MAJOR 0
-#define HSFLOW_VERSION_MINOR 4 /* 0.4: repeated asynchronous ITER|EPS solves pass the owed check on; E_NOTERM for EPS-only stalls */
+#define HSFLOW_VERSION_MINOR 5 /* 0.5: hsflow_multi_*, hsflow_slab_*, hsflow_set_row_origin, hsflow_get_info_ex */
 
 /* status codes (0 = success, like SDK_SUCCESS) */
 #define HSFLOW_OK 0
@@ -268,6 +268,42 @@ int hsflow_pipeline_info(hsflow_pipeline *pl, uint64_t ticket, hsflow_info *info
 int hsflow_pipeline_drain(hsflow_pipeline *pl);                 /* wait for everything submitted */
 int hsflow_pipeline_depth(hsflow_pipeline *pl);
 const char *hsflow_pipeline_last_error(hsflow_pipeline *pl);    /* pl may be NULL: create() error */
+
+/* --- several GPUs from one host process ----------------------------------------------------- */
+
+/* Independent pairs over the GPUs of a node (BASELINE config C4): one pair pipeline of `depth` slots per
+ * device, each driven by a host thread of its own; pair i goes to devices[i mod ndev]; no collective.  What the
+ * reference's run() did per pair on one device (HSOpticalFlowOpenCL.cpp:744-767), spread over the node.  A device may
+ * be listed more than once.  submit() never blocks on the device; the host buffers of a pair (page-locked for
+ * overlapped copies) belong to the library until wait(ticket) / drain() returned.  format: HSFLOW_FRAMES_*.
+ * Single-owner: submit / wait / drain / destroy from one thread. */
+typedef struct hsflow_multi hsflow_multi;
+int hsflow_multi_create(hsflow_multi **out, const int *devices, int ndev, int width, int height, int depth);
+int hsflow_multi_destroy(hsflow_multi *m); /* drains first; NULL accepted */
+int hsflow_multi_devices(hsflow_multi *m);
+int hsflow_multi_submit(hsflow_multi *m, int format, const uint8_t *prev, size_t prev_stride, const uint8_t *curr, size_t curr_stride,
+                        float *u, size_t u_stride, float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
+int hsflow_multi_wait(hsflow_multi *m, uint64_t ticket);
+int hsflow_multi_drain(hsflow_multi *m);
+const char *hsflow_multi_last_error(hsflow_multi *m); /* m may be NULL: create() error */
+
+/* ONE large frame in row slabs over several GPUs (BASELINE config C5): slab k holds a contiguous range
+ * of rows plus `halo` rows either side on devices[k]; the sweeps run in chunks of <= halo and after every chunk
+ * neighbouring slabs swap `halo` rows of u and v device to device (peer copies over xGMI, ordered by events; the host
+ * only enqueues) -- k-row halos every k sweeps instead of one row per sweep: the same bytes in k times fewer
+ * messages.  The result is bit-identical to the whole-frame solve on one GPU (hsflow_set_row_origin keeps each slab
+ * on the frame's checkerboard).  ITER termination, zero start.  A device may be listed more than once.  The
+ * one-process-per-GPU form of the same scheme, with RCCL send / recv, is opticalflowhs_amd/slab.py. */
+typedef struct hsflow_slab hsflow_slab;
+int hsflow_slab_create(hsflow_slab **out, const int *devices, int nslab, int width, int height, int halo);
+int hsflow_slab_destroy(hsflow_slab *s); /* NULL accepted */
+int hsflow_slab_count(hsflow_slab *s);
+int hsflow_slab_rows(hsflow_slab *s, int k, int *lo, int *hi); /* rows [lo, hi) slab k owns */
+int hsflow_slab_set_frames_u8(hsflow_slab *s, const uint8_t *prev, size_t prev_stride, const uint8_t *curr, size_t curr_stride);
+int hsflow_slab_solve(hsflow_slab *s, const hsflow_params *params); /* returns after every device finished */
+int hsflow_slab_exchanges(hsflow_slab *s);                          /* halo exchanges of the last solve */
+int hsflow_slab_get_flow(hsflow_slab *s, float *u, size_t u_stride, float *v, size_t v_stride);
+const char *hsflow_slab_last_error(hsflow_slab *s); /* s may be NULL: create() error */
 
 /* Planner introspection, no device needed: the kernel, sweeps per launch, tile shape, workgroup size,
  * tiles per launch, LDS bytes and launch count hsflow_solve would use for a context of this size with

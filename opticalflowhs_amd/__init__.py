@@ -9,8 +9,9 @@ from ._lib import (HsflowError, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL
                    TERM_EPS, TERM_ITER)
 from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, make_params, plan_query, term_criteria
 from .pipeline import PairPipeline, pinned_empty
+from .multi import MultiPairs, SlabFrame
 
-__all__ = ["HSFlow", "PairPipeline", "pinned_empty", "make_params", "plan_query", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
+__all__ = ["HSFlow", "PairPipeline", "MultiPairs", "SlabFrame", "pinned_empty", "make_params", "plan_query", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
            "TERM_ITER", "TERM_EPS", "MODE_CV", "MODE_CLASSIC", "MODE_CLASSIC_AS_SHIPPED", "KERNEL_AUTO", "KERNEL_SIMPLE",
            "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD", "OP_SLOTS_PER_PIXEL_SWEEP"]
 

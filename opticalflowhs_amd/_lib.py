@@ -89,6 +89,22 @@ PROTOTYPES = {
     "hsflow_pipeline_drain": (_i, [_vp]),
     "hsflow_pipeline_depth": (_i, [_vp]),
     "hsflow_pipeline_last_error": (ctypes.c_char_p, [_vp]),
+    "hsflow_multi_create": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i]),
+    "hsflow_multi_destroy": (_i, [_vp]),
+    "hsflow_multi_devices": (_i, [_vp]),
+    "hsflow_multi_submit": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
+    "hsflow_multi_wait": (_i, [_vp, ctypes.c_uint64]),
+    "hsflow_multi_drain": (_i, [_vp]),
+    "hsflow_multi_last_error": (ctypes.c_char_p, [_vp]),
+    "hsflow_slab_create": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i]),
+    "hsflow_slab_destroy": (_i, [_vp]),
+    "hsflow_slab_count": (_i, [_vp]),
+    "hsflow_slab_rows": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "hsflow_slab_set_frames_u8": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "hsflow_slab_solve": (_i, [_vp, _pp]),
+    "hsflow_slab_exchanges": (_i, [_vp]),
+    "hsflow_slab_get_flow": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "hsflow_slab_last_error": (ctypes.c_char_p, [_vp]),
     "hsflow_calc_optical_flow_hs_8u32f": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i,
                                                ctypes.c_float, _i, _i, ctypes.c_double]),
 }
