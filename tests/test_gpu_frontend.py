@@ -286,6 +286,11 @@ def test_cli_on_the_reference_jpegs_reproduces_its_pictures(hs, gpu_ok, tmp_path
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cv_out.jpg" % name), "rb").read()
     _cli(["-cl", "-hd", a, b, out, "15", "10", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_%s_cl_out.jpg" % name), "rb").read()
+    if name == "bunny":
+        # the reference's fifth picture (Release/bunny_cl_out.jpg): the same command line with TWO iterations
+        # (tools/scan_release_bunny.py found them) -- again the very same file
+        _cli(["-cl", "-hd", a, b, out, "15", "2", "1", "GPU"], tmp_path, {"HSFLOW_CL_AS_SHIPPED": "1"})
+        assert open(out, "rb").read() == open(os.path.join(GOLDEN, "ref_bunny_cl_out_release.jpg"), "rb").read()
 
 
 def test_cv_camera_route_matches_the_reference_loop(hs, oracle, gpu_ok, tmp_path):

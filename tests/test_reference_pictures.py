@@ -51,6 +51,28 @@ def test_oracle_reproduces_the_opencl_route_pictures(oracle, name):
         assert wrong2 > 200 and q2 < 40.0, (label, wrong2, q2)
 
 
+def test_oracle_reproduces_the_fifth_picture_two_sweeps(oracle):
+    """The reference holds a second OpenCL-route picture of the bunny pair, Release/bunny_cl_out.jpg (kept as
+    tests/golden/ref_bunny_cl_out_release.jpg).  A scan (tools/scan_release_bunny.py, profiles/r02_release_bunny_scan.txt:
+    42 228 parameter combinations) has one exact optimum: Kernels.cl as shipped, alpha 15 and TWO sweeps -- there the
+    drawing saved as JPEG decodes to the picture with no pixel different.  A second, independent pin of the classic
+    discretisation (derivative cube, 1/6-1/12 mean, alpha^2, the missing v update) at another sweep count."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    import os
+    ref = np.asarray(Image.open(os.path.join(refpics.GOLDEN, "ref_bunny_cl_out_release.jpg")).convert("RGB")).astype(np.int32)
+    A, B = refpics.gray_pair("bunny")
+
+    def wrong(alpha, it, upd):
+        u, v = oracle.classic_flow(A, B, alpha, it, update_v=upd)
+        ours = refpics.through_jpeg(refpics.render(u, v, "cl")).astype(np.int32)
+        return int((np.abs(ours - ref).max(axis=2) > 4).sum())
+
+    assert wrong(refpics.ALPHA, 2, False) == 0
+    for alpha, it, upd in ((refpics.ALPHA, 1, False), (refpics.ALPHA, 3, False), (14.0, 2, False), (16.0, 2, False), (refpics.ALPHA, 2, True)):
+        assert wrong(alpha, it, upd) > 200, (alpha, it, upd)
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_grid_decisions_without_a_jpeg_codec(oracle, name):
     """Same check from the committed blue / red levels only (no PIL): all clear decisions agree but
