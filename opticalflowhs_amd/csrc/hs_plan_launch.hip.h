@@ -384,6 +384,28 @@ bool make_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JP
     return make_plan(c, T, p.tile_w, p.tile_h, p.threads, out.f);
 }
 
+// A plan for T sweeps that witness launches can use: the planner's own choice if it qualifies, else the first shape
+// (rows per lane, wavefronts) that does, as far as the caller left those open.  Only thin frames and very short
+// launches need the search (a core tile thinner than a strip).
+bool make_witness_jplan(const hsflow_ctx *c, int kind, int T, const hsflow_params &p, JPlan &out)
+{
+    if (make_jplan(c, kind, T, p, out) && strip_has_witness(out)) return true;
+    if (kind != HSFLOW_KERNEL_STRIP && kind != HSFLOW_KERNEL_FOLD) return false;
+    static const int order[8] = {5, 4, 6, 3, 2, 8, 7, 1};
+    for (int R : order) {
+        if (p.strip_rows && p.strip_rows != R) continue;
+        for (int NW = 16; NW >= 1; NW--) {
+            if (p.threads && p.threads != NW * 64) continue;
+            hsflow_params q = p;
+            q.strip_rows = R;
+            q.threads = NW * 64;
+            JPlan alt;
+            if (make_jplan(c, kind, T, q, alt) && strip_has_witness(alt)) { out = alt; return true; }
+        }
+    }
+    return false;
+}
+
 // eps: 0 none, 1 Eps of every sweep, 2 witness (strip / fold: one lower bound per launch), 3 witness + the exact Eps
 // of the last sweep (two words per workgroup)
 // deriv: this launch also does the derivative pass (only where strip_deriv_fusable() said so)

@@ -198,6 +198,7 @@ struct SolveSetup {
     long long budget;   // sweep budget (huge when ITER does not apply)
     int T;              // sweeps per full launch
     JPlan plan;         // launch plan for T sweeps
+    hsflow_params eff;  // the caller's parameters as the solve paths use them (strip_rows may have been fixed, see prepare_solve)
 };
 
 // ITER termination: a fixed sweep count, nothing on the host between launches (optionally one hipGraph).
@@ -287,6 +288,10 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
     const bool has_tail = multi && iters % T;
     if (has_tail) {
         if (!make_jplan(c, kernel, iters % T, p, tailp)) return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for a chunk");
+        if (witness && !strip_has_witness(tailp)) { // as in prepare_solve
+            JPlan alt;
+            if (make_witness_jplan(c, kernel, iters % T, p, alt)) tailp = alt;
+        }
         stride = std::max(stride, plan_eps_stride(kernel, tailp));
         // (a tail of one sweep is measured, not witnessed: the synchronous pass's mode 3; an asynchronous pass needs it able)
         if (witness && (async || iters % T > 1) && !strip_has_witness(tailp)) witness = false;
@@ -619,6 +624,7 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
 
     int T = 1;
     JPlan plan;
+    hsflow_params eff = p;
     if (multi) {
         const int horizon = budget > (1 << 30) ? 64 : (int)budget; // EPS-only runs: plan for chunks
         if (p.fuse_steps > 0) T = std::min(p.fuse_steps, kMaxFuse);
@@ -633,13 +639,21 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
         if ((kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && coeff < 1e-20f) T = std::min(T, 8);
         if (!make_jplan(c, kernel, T, p, plan))
             return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the requested tile/threads/rows/fuse_steps");
+        // ITER|EPS runs witness launches, which watch an edge row of each strip: a plan whose core tile is thinner
+        // than a strip may have no wavefront with a core row there (thin frames, very short launches); another shape
+        // then takes its place as far as the caller left rows / wavefronts open (make_witness_jplan).
+        if (use_eps && use_iter && p.max_iter > 0 && (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) &&
+            !strip_has_witness(plan)) {
+            JPlan alt;
+            if (make_witness_jplan(c, kernel, T, p, alt)) plan = alt;
+        }
         plan_to_info(c, plan);
     } else {
         c->info.fuse_steps = 1; c->info.tile_w = c->info.tile_h = 0; c->info.threads = 256;
         c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
     }
     c->info.kernel = kernel;
-    S = SolveSetup{coeff, kernel, multi, use_iter, use_eps, budget, T, plan};
+    S = SolveSetup{coeff, kernel, multi, use_iter, use_eps, budget, T, plan, eff};
     return HSFLOW_OK;
 }
 
@@ -670,10 +684,10 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;
     c->info.last_eps = 0.f;
     Profiler prof{c, p.profile != 0};
-    if (!S.use_eps) return solve_fixed(c, p, S, prof, async);
+    if (!S.use_eps) return solve_fixed(c, S.eff, S, prof, async);
     constexpr long long kSpecMax = 1 << 16; // speculative ITER|EPS: the whole budget in one go
-    if (S.use_iter && p.max_iter > 0 && S.budget <= kSpecMax) return solve_iter_eps(c, p, S, prof, async);
-    return solve_eps_chunks(c, p, S, prof);
+    if (S.use_iter && p.max_iter > 0 && S.budget <= kSpecMax) return solve_iter_eps(c, S.eff, S, prof, async);
+    return solve_eps_chunks(c, S.eff, S, prof);
 }
 
 int copy_frame_in(hsflow_ctx *c, uint8_t *dst, const void *src, size_t stride, hipMemcpyKind kind, bool sync)

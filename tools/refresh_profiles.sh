@@ -1,16 +1,16 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): everything the numbers in DESIGN.md section 6 and profiles/ are quoted from.
 # Outputs under gpurun_out/refresh/ ; copy into profiles/ with the names profiles/README.md lists.
-# usage: tools/refresh_profiles.sh [tag]          (default tag r01)
+# usage: tools/refresh_profiles.sh [tag]          (default tag r02)
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p "$OUT"
 cd "$ROOT"
 run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
 run python bench.py > "$OUT/bench_1080p.json" 2> "$OUT/bench_1080p.err" || exit 1
-run python bench.py --iter-eps --skip-cpu > "$OUT/bench_1080p_itereps.json" 2>> "$OUT/err.txt" || exit 2
+run python bench.py --sync-solves --skip-cpu > "$OUT/bench_1080p_sync_solves.json" 2>> "$OUT/err.txt" || exit 2
 run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5 --skip-cpu > "$OUT/bench_4k.json" 2>> "$OUT/err.txt" || exit 3
 {
   echo "# 16 pairs per step (C4 shard of one GPU)";      run python bench.py --pairs 16 --steps 30 --warmup 5 --skip-cpu 2>> "$OUT/err.txt" || exit 4
@@ -24,6 +24,10 @@ run python tools/bench_classic.py > "$OUT/bench_classic.txt" 2>> "$OUT/err.txt" 
 run python tools/bench_e2e.py > "$OUT/e2e_pipeline.txt" 2>> "$OUT/err.txt" || exit 10
 { run python tools/crossover.py 100; run python tools/crossover.py 10; } > "$OUT/crossover.txt" 2>> "$OUT/err.txt" || exit 11
 run python tools/time_cases.py > "$OUT/time_cases.txt" 2>> "$OUT/err.txt" || exit 12
+run python tools/stamps.py --configs "20:5:1024;14:5:1024;12:4:1024" > "$OUT/phase_stamps.txt" 2>> "$OUT/err.txt" || exit 15
+run env HSFLOW_BENCH_BACKEND=gloo MASTER_ADDR=127.0.0.1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 \
+    bench.py --gpus 2 --steps 20 --warmup 5 --c4-pairs 32 --c5-size 4096 --c5-iters 100 > "$OUT/bench_2rank_gloo_rehearsal.json" 2>> "$OUT/err.txt" || exit 16
 run bash tools/profile_gpu.sh "$TAG" > "$OUT/prof.log" 2>&1 || exit 13
 run bash tools/profile_gpu.sh "${TAG}_4k" --width 3840 --height 2160 --iters 200 > "$OUT/prof_4k.log" 2>&1 || exit 14
+run bash tools/profile_sq.sh "$TAG" --no-side --blocks 1 > "$OUT/prof_sq.log" 2>&1 || exit 17
 echo done
