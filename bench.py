@@ -263,6 +263,9 @@ def main():
         barrier()
         return reduce_max(time.perf_counter() - t0)
 
+    if args.kernel in ("simple", "fused") and not args.sync_solves:
+        # asynchronous ITER|EPS rests on the strip / fold kernels' witness launches; these two kernels are timed ITER only
+        args.iter_only, args.no_side = True, True
     head_p, side_p = (p_iter, p_ieps) if args.iter_only else (p_ieps, p_iter)
     head_name, side_name = ("ITER", "ITER|EPS (eps 1e-6)") if args.iter_only else ("ITER|EPS (eps 1e-6)", "ITER")
     step = stepper(head_p)
@@ -319,7 +322,8 @@ def main():
     # VALU issue is what binds the multi-sweep kernels: several sweeps run per launch out of registers, so the
     # 28 B/pixel/sweep of SURVEY.md 8d are not what HBM moves (kept below as hbm_algorithmic; it exceeds the HBM
     # peak and is no bound).  op slots = wave64 VALU lane-operations the update needs per pixel and sweep as the
-    # kernels compute it (hsflow_info... see OP_SLOTS below); peak = all SIMDs issuing one such operation per
+    # kernels compute it (opticalflowhs_amd.OP_SLOTS_PER_PIXEL_SWEEP: 9 with the shared cross sums; the straightforward
+    # form costs 11, reported beside it as frac_at_11_op_slots); peak = all SIMDs issuing one such operation per
     # MEASURED_CYCLES_PER_WAVE64_OP cycles at the clock the chip holds under this kernel.
     op_slots = hs.OP_SLOTS_PER_PIXEL_SWEEP
     lane_ops_per_launch = op_slots * px * sweeps_per_launch
@@ -341,6 +345,7 @@ def main():
             "peak_Tlaneops_measured_issue": peak_measured, "peak_Tlaneops_spec": peak_spec,
             "frac_of_measured_issue": achieved_valu / peak_measured, "frac_of_spec": achieved_valu / peak_spec,
             "ideal_us_per_step": ideal_us_per_step, "jacobi_kernel_us_per_step": jac_us_per_step,
+            "frac_at_11_op_slots": hs.OP_SLOTS_PER_PIXEL_SWEEP_STRAIGHTFORWARD / float(op_slots) * achieved_valu / peak_measured,
             "constants": {"simds": N_SIMD, "cycles_per_wave64_op_measured": MEASURED_CYCLES_PER_WAVE64_OP,
                           "clock_ghz_measured": MEASURED_CLOCK_GHZ, "cycles_per_wave64_op_spec": SPEC_CYCLES_PER_WAVE64_OP,
                           "clock_ghz_spec": SPEC_CLOCK_GHZ,

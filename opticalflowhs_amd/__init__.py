@@ -16,8 +16,11 @@ __all__ = ["HSFlow", "PairPipeline", "MultiPairs", "SlabFrame", "pinned_empty", 
            "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD", "OP_SLOTS_PER_PIXEL_SWEEP"]
 
 # Wave64 VALU lane-operations one pixel costs per Jacobi sweep in the multi-sweep kernels' arithmetic (csrc/hs_kernels_strip.hip.h,
-# strip_row_update): 3 + 3 additions for the two neighbour sums, 4 fused multiply-adds for the update, 1 multiplication that
-# carries the constant term to the next sweep's scale.  bench.py prices the VALU-issue roofline with it.
-OP_SLOTS_PER_PIXEL_SWEEP = 11
+# cross_rows + strip_row_update): 2 + 2 additions for the two neighbour sums (one shared diagonal cross sum and one combining
+# addition per plane), 4 fused multiply-adds for the update, 1 multiplication that carries the constant term to the next sweep's
+# scale.  bench.py prices the VALU-issue roofline with it.  The straightforward form of the same update (3 + 3 additions, round 1)
+# costs 11; bench.py reports the fraction at that accounting beside it so that rounds stay comparable.
+OP_SLOTS_PER_PIXEL_SWEEP = 9
+OP_SLOTS_PER_PIXEL_SWEEP_STRAIGHTFORWARD = 11
 
 _lib.load()  # fail loudly at import time if the HIP library is absent
