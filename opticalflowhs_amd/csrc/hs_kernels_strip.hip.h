@@ -319,59 +319,58 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // Tiles that do not (the vast majority) load with plain aligned 16-byte accesses only.
     const int rx0 = bx * g.CW - g.HX;
     const bool xedge = !(rx0 >= 0 && rx0 + 256 <= g.W);
-    if (!xedge) {
+    // Where does this lane read its four columns?  Inside the image: at x0.  A group that lies completely outside the
+    // image on the left mirrors onto an aligned group read backwards (columns -1-k <-> k); the same holds on the right
+    // when W % 4 == 0: those lanes keep the 16-byte loads (from the mirrored address, components reversed afterwards).
+    // Only groups that straddle column W-1 or sit right of it when W % 4 != 0 (and images narrower than the halo) need
+    // four reflected scalar loads per plane ("slow").  ALL rows' loads are issued first, branch-free -- edge tiles then
+    // load as fast as interior ones (with a branch per row their loads did not overlap: +5 000 cycles per launch on
+    // the two edge tile columns, which every launch then waited for) -- and the fix-ups follow.
+    int xg = x0;
+    bool xrev = false, slow = false;
+    if (xedge && !xin) {
+        if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; xrev = true; }
+        else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; xrev = true; }
+        else { xg = 0; slow = true; }
+    }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const long long off = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P + x0;
-            lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!g.zero_in) {
-                lu[r] = *(const float4 *)(u_in + off);
-                lv[r] = *(const float4 *)(v_in + off);
-            }
-            if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
+    for (int r = 0; r < R; r++) {
+        const long long off = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P + xg;
+        lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lc[r] = make_uint4(0u, 0u, 0u, 0u);
+        if (!g.zero_in) {
+            lu[r] = *(const float4 *)(u_in + off);
+            lv[r] = *(const float4 *)(v_in + off);
         }
-    } else {
+        if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
+    }
+    if (xedge) { // workgroup-uniform
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const long long row = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P;
-            // A group that lies completely outside the image on the left mirrors onto an aligned
-            // group read backwards (columns -1-k <-> k); the same holds on the right when W % 4 == 0.
-            // Those lanes keep the 16-byte loads (from the mirrored address, components reversed).
-            // Only groups that straddle column W-1 or sit right of it when W % 4 != 0 (and images
-            // narrower than the halo) fall back to four reflected scalar loads per plane.
-            int xg = x0;
-            bool rev = false, slow = false;
-            if (!xin) {
-                if (x0 < 0 && -x0 <= g.W) { xg = -x0 - 4; rev = true; }
-                else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
-                else { xg = 0; slow = true; }
+            if (xrev) {
+                lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
+                lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
+                lc[r] = make_uint4(lc[r].w, lc[r].z, lc[r].y, lc[r].x);
             }
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (!g.zero_in) {
-                a = *(const float4 *)(u_in + row + xg);
-                b = *(const float4 *)(v_in + row + xg);
-            }
-            uint4 c = make_uint4(0u, 0u, 0u, 0u);
-            if (!DERIV) c = *(const uint4 *)(coef + row + xg);
-            if (rev) {
-                a = make_float4(a.w, a.z, a.y, a.x);
-                b = make_float4(b.w, b.z, b.y, b.x);
-                c = make_uint4(c.w, c.z, c.y, c.x);
-            }
-            if (slow) { // volatile keeps this a separate, rarely taken path
-                const volatile float *uv = u_in + row, *vv = v_in + row;
+        }
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) { // wave-uniform: rare (W % 4 != 0, or an image narrower than the halo)
+            if (slow) {
                 const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
                           xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-                if (!g.zero_in) {
-                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
-                }
-                if (!DERIV) {
-                    const volatile uint32_t *cv = coef + row;
-                    c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const long long row = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P;
+                    if (!g.zero_in) {
+                        const float *uv = u_in + row, *vv = v_in + row;
+                        lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                        lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                    }
+                    if (!DERIV) {
+                        const uint32_t *cv = coef + row;
+                        lc[r] = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                    }
                 }
             }
-            lu[r] = a; lv[r] = b; lc[r] = c;
         }
     }
     if (DERIV) strip_derive<R>(fA, fB, g, base, x0, rev ? y0 + R - 1 : y0, rev ? -1 : 1, xin, lc);
@@ -569,6 +568,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #if !(HS_DIAG & 2) /* diagnostic build: no barrier */
         if (s + 1 < g.T) __syncthreads();
 #endif
+        // diagnostic (stamps != NULL only): when each sweep ended -- all wavefronts leave the barrier together, so
+        // wavefront 0 sees the workgroup's sweep times; slots behind the 8 phase stamps of every workgroup
+        if (stamps && gridDim.x <= 8192 && threadIdx.x == 0)
+            stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 32 + (s & 31)] = __builtin_amdgcn_s_memtime();
     };
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
 #if HS_UNGATED_CORE
@@ -757,38 +760,48 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         else if (x0 >= g.W && (g.W & 3) == 0 && 2 * g.W - x0 - 4 >= 0) { xg = 2 * g.W - x0 - 4; rev = true; }
         else { xg = 0; slow = true; }
     }
+    // all rows' loads first, branch-free; then the fix-ups of the side tiles (k_jacobi_strip explains why)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int y = yb + (lower ? 2 * R - 1 - r : r);
-        const long long row = base + (long long)mirror_index(y, g.H) * g.P;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        const long long off = base + (long long)mirror_index(y, g.H) * g.P + xg;
+        lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lc[r] = make_uint4(0u, 0u, 0u, 0u);
         if (!g.zero_in) {
-            a = *(const float4 *)(u_in + row + xg);
-            b = *(const float4 *)(v_in + row + xg);
+            lu[r] = *(const float4 *)(u_in + off);
+            lv[r] = *(const float4 *)(v_in + off);
         }
-        uint4 c = make_uint4(0u, 0u, 0u, 0u);
-        if (!DERIV) c = *(const uint4 *)(coef + row + xg);
-        if (side) {
+        if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
+    }
+    if (side) { // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < R; r++) {
             if (rev) {
-                a = make_float4(a.w, a.z, a.y, a.x);
-                b = make_float4(b.w, b.z, b.y, b.x);
-                c = make_uint4(c.w, c.z, c.y, c.x);
+                lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
+                lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
+                lc[r] = make_uint4(lc[r].w, lc[r].z, lc[r].y, lc[r].x);
             }
-            if (slow) { // volatile keeps this a separate, rarely taken path
-                const volatile float *uv = u_in + row, *vv = v_in + row;
+        }
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) { // wave-uniform, rare
+            if (slow) {
                 const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
                           xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-                if (!g.zero_in) {
-                    a = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                    b = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
-                }
-                if (!DERIV) {
-                    const volatile uint32_t *cv = coef + row;
-                    c = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int y = yb + (lower ? 2 * R - 1 - r : r);
+                    const long long row = base + (long long)mirror_index(y, g.H) * g.P;
+                    if (!g.zero_in) {
+                        const float *uv = u_in + row, *vv = v_in + row;
+                        lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                        lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                    }
+                    if (!DERIV) {
+                        const uint32_t *cv = coef + row;
+                        lc[r] = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                    }
                 }
             }
         }
-        lu[r] = a; lv[r] = b; lc[r] = c;
     }
     // (the wave shifts in strip_derive cross the lane 31/32 seam like those of the sweep: region-edge columns)
     if (DERIV) strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);

@@ -212,6 +212,18 @@ void dump_stamps(hsflow_ctx *c, int tiles)
         fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0],
                 o[5] - o[4], o[6], o[7]);
     }
+    // per-sweep end stamps of the strip kernel (cycles since the end of the load phase), HSFLOW_DEBUG_STAMPS_SWEEPS=1
+    if (getenv("HSFLOW_DEBUG_STAMPS_SWEEPS") && tiles <= 8192 && c->info.kernel == HSFLOW_KERNEL_STRIP) {
+        const int T = std::min(c->info.fuse_steps, 32);
+        std::vector<unsigned long long> sw((size_t)tiles * 32);
+        if (hipMemcpy(sw.data(), c->dStamps + (size_t)tiles * 8, sw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int i = 0; i < tiles; i++) {
+                fprintf(f, "S %d", i);
+                for (int k = 0; k < T; k++) fprintf(f, " %llu", sw[(size_t)i * 32 + k] - h[(size_t)i * 8 + 1]);
+                fprintf(f, "\n");
+            }
+        }
+    }
     fclose(f);
 }
 
