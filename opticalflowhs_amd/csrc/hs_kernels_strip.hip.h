@@ -30,6 +30,9 @@
 #ifndef HS_UNGATED_CORE
 #define HS_UNGATED_CORE 0 /* experiment, rejected: two copies of the sweep body make the register allocator spill 66 registers */
 #endif
+#ifndef HS_SWEEP_STAMPS
+#define HS_SWEEP_STAMPS 0
+#endif
 #ifndef HS_DIAG /* bit mask of diagnostic knobs in the strip sweep (timing experiments only, results are wrong): 1 no LDS
                    exchange, 2 no barrier, 4 no trapezoid gating, 8 no arithmetic */
 #define HS_DIAG 0
@@ -476,6 +479,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     const int wd = rev ? wa : wb, sd = rev ? sa : sb;
     int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
                     // loop-carried flag makes the register allocator spill inside the loop)
+    const unsigned long long wit_mask = (rowcore & 1u) ? __builtin_amdgcn_ballot_w64(lanecore) : 0ull; // lanes whose answer counts
     // One sweep.  EM is the Eps mode of THIS sweep: the launch's own (EPS 0, 1, 2), or for EPS == 3 witness
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
@@ -492,8 +496,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #endif
         // HS_SCALED: this sweep takes the flow from scale 4^s to 4^(s+1)
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
-        // (wave-uniform: kept in a scalar register, the sweep loop has no vector register to spare)
-        const float thr_s = HS_SCALED ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_ldexpf(eps_thr, 2 * (s + 1))))) : eps_thr;
+        // eps_thr * 4^(s+1) by integer arithmetic on the exponent: scalar instructions only (v_ldexp + v_readfirstlane put
+        // a vector-to-scalar round trip into every sweep).  Exact for a normal eps_thr; eps_thr = 0 or a product beyond
+        // the float range merely makes the witness fail, and the exact pass decides (the host never sends a denormal).
+        const float thr_s = HS_SCALED ? __int_as_float(__float_as_int(eps_thr) + ((s + 1) << 24)) : eps_thr;
 #if HS_DIAG & 1 /* diagnostic build (wrong results): no LDS traffic, the strip's own edge rows stand in */
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);
         const float4 du4 = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y), dv4 = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);
@@ -521,8 +527,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         HS_ROW(0, E0, s0, sA);
         // witness: did u change by >= eps_thr at column x0 of register row 0 (where that is a core row) in any lane?
         // (The host runs witness launches only with plans in which some wavefront has such a row: strip_has_witness.)
-        if (EM == 2 && (rowcore & 1u))
-            seen_n += __builtin_amdgcn_ballot_w64(lanecore && fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
+        if (EM == 2) // (wit_mask: the core lanes if register row 0 is a core row, else none -- no branch, two scalar instructions)
+            seen_n += (__builtin_amdgcn_ballot_w64(fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) & wit_mask) != 0 ? 1 : 0;
         if (R >= 2) {
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
@@ -570,8 +576,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #endif
         // diagnostic (stamps != NULL only): when each sweep ended -- all wavefronts leave the barrier together, so
         // wavefront 0 sees the workgroup's sweep times; slots behind the 8 phase stamps of every workgroup
+#if HS_SWEEP_STAMPS /* (diagnostic builds: tools/diag_build.sh; tools/stamps_sweeps.py reads them) */
         if (stamps && gridDim.x <= 8192 && threadIdx.x == 0)
             stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 32 + (s & 31)] = __builtin_amdgcn_s_memtime();
+#endif
     };
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
 #if HS_UNGATED_CORE
@@ -878,12 +886,13 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     const int wo = lower ? (w < NW - 1 ? w + 1 : w) : (w > 0 ? w - 1 : w);
     const int ho = lower ? (w < NW - 1 ? 0 : 1) : (w > 0 ? 1 : 0);
     int seen_n = 0; // EPS == 2: sweeps in which some lane of this wavefront saw a change >= eps_thr
+    const unsigned long long wit_mask = __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore); // lanes whose answer counts
     // one sweep in Eps mode EM (k_jacobi_strip explains EPS == 3: witness sweeps, then one measured sweep)
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
         const int last = g.T - 1 - s; // rows with rdist <= last are still swept
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
-        const float thr_s = HS_SCALED ? __builtin_ldexpf(eps_thr, 2 * (s + 1)) : eps_thr;
+        const float thr_s = HS_SCALED ? __int_as_float(__float_as_int(eps_thr) + ((s + 1) << 24)) : eps_thr; // (see k_jacobi_strip)
         const float4 *eo = HF_SLOT(s & 1, wo, ho) + hl;
         const float4 h4u = eo[0], h4v = eo[32];
         const f2 ouP_ = f2{h4u.x, h4u.y}, ouQ_ = f2{h4u.z, h4u.w}, ovP_ = f2{h4v.x, h4v.y}, ovQ_ = f2{h4v.z, h4v.w};
@@ -914,7 +923,7 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
             if (r == 0) {
                 // witness (k_jacobi_strip explains it): old and new value of the published row at column x0
                 if (EM == 2)
-                    seen_n += __builtin_amdgcn_ballot_w64((rowcore & 1u) && lanecore && fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) != 0 ? 1 : 0;
+                    seen_n += (__builtin_amdgcn_ballot_w64(fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) & wit_mask) != 0 ? 1 : 0;
                 if (s + 1 < g.T) HF_PUBLISH((s + 1) & 1);
             }
             sp = sc;

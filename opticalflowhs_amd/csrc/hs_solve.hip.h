@@ -311,6 +311,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         // threshold as the smallest float >= epsilon: "change >= epsThr" then implies "Eps >= epsilon"
         c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
         if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
+        if (c->epsThr < FLT_MIN) c->epsThr = c->epsThr > 0.f ? FLT_MIN : 0.f; // the kernels scale it through its exponent bits
         const int n_launch = (iters + T - 1) / T;
         const int last_chunk = iters - (n_launch - 1) * T;
         // Synchronous solves report last_eps at once: their last launch measures its final sweep (mode 3: two words

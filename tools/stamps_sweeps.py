@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-sweep durations inside one strip-kernel launch (HSFLOW_DEBUG_STAMPS + HSFLOW_DEBUG_STAMPS_SWEEPS): median over the
-workgroups of the cycles each sweep of the last launch took.  Diagnosis only."""
+workgroups of the cycles each sweep of the last launch took.  Diagnosis only: needs a library built with
+-DHS_SWEEP_STAMPS=1 (tools/diag_build.sh 0; HSFLOW_LIB_PATH=tools/bin/libhsflow_diag0.so)."""
 import os
 import sys
 import tempfile
