@@ -137,6 +137,18 @@ __device__ __forceinline__ float wave_max_nonneg(float x)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
+// Sum of lanes 0..15 (the other lanes must hold 0), returned wave-uniform: row_shr prefix sums leave it in lane 15.
+__device__ __forceinline__ float wave_sum16(float x)
+{
+#define HS_DPP_ADD(ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, true))
+    HS_DPP_ADD(0x111); // row_shr:1
+    HS_DPP_ADD(0x112); // row_shr:2
+    HS_DPP_ADD(0x114); // row_shr:4
+    HS_DPP_ADD(0x118); // row_shr:8
+#undef HS_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 15));
+}
+
 // ------------------------------------------------------------------------------------------
 // a1: derivative pass, CV mode.  One lane = 4 consecutive pixels of one row.
 //     reads 2 B/pixel (u8 A with a 3x3 neighbourhood from L1/L2, u8 B), writes 4 B/pixel.

@@ -480,6 +480,15 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
                     // loop-carried flag makes the register allocator spill inside the loop)
     const unsigned long long wit_mask = (rowcore & 1u) ? __builtin_amdgcn_ballot_w64(lanecore) : 0ull; // lanes whose answer counts
+    // Who looks, and when: the wavefronts whose rows are all core rows take turns, one of them per sweep (a sweep
+    // needs ONE witness in the workgroup; sixteen wavefronts looking in every sweep cost 4 % of the launch).  A
+    // workgroup without such a wavefront (thin cores, clipped bottom tiles) keeps the old rule: every wavefront whose
+    // register row 0 is a core row looks in every sweep.  wit_cnt counts down to this wavefront's next turn.
+    const int core_here = min(g.CH, g.H - by * g.CH);
+    const int wit_lo = (g.T + R - 1) / R, wit_n = (g.T + core_here) / R - wit_lo; // wavefronts wit_lo .. wit_lo + wit_n - 1
+    const bool wit_rot = wit_n > 0;
+    const int wit_per = wit_rot ? wit_n : 1;
+    int wit_cnt = !wit_rot ? 0 : (w >= wit_lo && w < wit_lo + wit_n) ? w - wit_lo : (1 << 30);
     // One sweep.  EM is the Eps mode of THIS sweep: the launch's own (EPS 0, 1, 2), or for EPS == 3 witness
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
@@ -514,7 +523,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         float e = 0.f;
         constexpr int EL = E0 ^ ((R - 1) & 1); // parity of the last register row
         Cross sA, s0, sK, sL; // above row 0, below row 0, above row R-1, below row R-1
-        const float w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
+        const bool wturn = EM == 2 && wit_cnt == 0; // wave-uniform: this wavefront is the sweep's witness
+        float w0 = 0.f;
+        if (wturn) w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
         // --- first row (the strip's upper edge)
         if (HS_ACT(0)) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
         if (!GATED) __builtin_amdgcn_sched_barrier(0);
@@ -527,8 +538,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         HS_ROW(0, E0, s0, sA);
         // witness: did u change by >= eps_thr at column x0 of register row 0 (where that is a core row) in any lane?
         // (The host runs witness launches only with plans in which some wavefront has such a row: strip_has_witness.)
-        if (EM == 2) // (wit_mask: the core lanes if register row 0 is a core row, else none -- no branch, two scalar instructions)
-            seen_n += (__builtin_amdgcn_ballot_w64(fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) & wit_mask) != 0 ? 1 : 0;
+        if (EM == 2) { // (wit_mask: the core lanes if register row 0 is a core row, else none)
+            if (wturn) seen_n += (__builtin_amdgcn_ballot_w64(fabsf(HS_DIFF1(w0, uP[0].x)) >= thr_s) & wit_mask) != 0 ? 1 : 0;
+            wit_cnt = wturn ? wit_per - 1 : wit_cnt - 1;
+        }
         if (R >= 2) {
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
@@ -618,11 +631,13 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
     if (EPS == 2 || EPS == 3) {
         const int witnessed = EPS == 3 ? g.T - 1 : g.T; // sweeps that ran in witness mode
-        if (lane == 0) eps_lds[w] = (seen_n == witnessed && (rowcore & 1u)) ? __builtin_inff() : 0.f;
+        // sweeps this wavefront vouches for; taking turns they add up to the launch, otherwise one wavefront must have all
+        if (lane == 0) eps_lds[w] = (float)seen_n;
         __syncthreads();
         if (w == 0) {
-            const float y = wave_max_nonneg(lane < NW ? eps_lds[lane] : 0.f);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(y);
+            const float x = lane < NW ? eps_lds[lane] : 0.f;
+            const float n = wit_rot ? wave_sum16(x) : wave_max_nonneg(x);
+            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(n == (float)witnessed ? __builtin_inff() : 0.f);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
                 if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
