@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsflow.so")
 SOURCES = ["hsflow.hip", "pair_pipeline.cpp", "multi_gpu.cpp"]
-DEPS = ["hsflow.hip", "pair_pipeline.cpp", "multi_gpu.cpp", "hs_context.hip.h", "hs_plan_launch.hip.h", "hs_runtime.hip.h", "hs_solve.hip.h", "hs_kernels.hip.h", "hs_kernels_strip.hip.h", "hs_kernels_pre.hip.h", "hs_kernels_classic.hip.h", os.path.join("..", "..", "include", "hsflow.h")]
+DEPS = ["hsflow.hip", "pair_pipeline.cpp", "multi_gpu.cpp", "hs_context.hip.h", "hs_plan_launch.hip.h", "hs_runtime.hip.h", "hs_solve.hip.h", "hs_kernels.hip.h", "hs_kernels_strip.hip.h", "hs_kernels_pre.hip.h", "hs_kernels_classic.hip.h", "hs_kernels_classic_strip.hip.h", os.path.join("..", "..", "include", "hsflow.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine",
          "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage"]
 

@@ -99,7 +99,7 @@ hipError_t launch_fused(const hsflow_ctx *c, const FusedPlan &p, bool eps, int l
 
 template <int NT, int K>
 hipError_t launch_classic_fused_t(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
-                                  float *uo, float *vo, float alpha2)
+                                  float *uo, float *vo, float alpha2, bool configure_only)
 {
     auto kern = write_v ? hsk::k_jacobi_classic_fused<NT, K, true> : hsk::k_jacobi_classic_fused<NT, K, false>;
     static bool configured[2][64] = {};
@@ -109,19 +109,125 @@ hipError_t launch_classic_fused_t(const hsflow_ctx *c, const FusedPlan &p, bool 
         if (e != hipSuccess) return e;
         configured[write_v][c->device & 63] = true;
     }
+    if (configure_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(NT), p.lds_bytes, c->stream, c->dE[0], c->dE[1], c->dE[2], ui, vi, uo, vo, p.g, alpha2);
     return hipGetLastError();
 }
 
 hipError_t launch_classic_fused(const hsflow_ctx *c, const FusedPlan &p, bool write_v, const float *ui, const float *vi,
-                                float *uo, float *vo, float alpha2)
+                                float *uo, float *vo, float alpha2, bool cfg = false)
 {
 #define HS_CASE(NT_, K_)                                                                          \
-    if (p.NT == NT_ && p.K == K_) return launch_classic_fused_t<NT_, K_>(c, p, write_v, ui, vi, uo, vo, alpha2);
+    if (p.NT == NT_ && p.K == K_) return launch_classic_fused_t<NT_, K_>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
     HS_CASE(1024, 1) HS_CASE(1024, 2) HS_CASE(1024, 3)
     HS_CASE(512, 1) HS_CASE(512, 2) HS_CASE(512, 3) HS_CASE(512, 4)
     HS_CASE(256, 1) HS_CASE(256, 2) HS_CASE(256, 3) HS_CASE(256, 4)
 #undef HS_CASE
+    return hipErrorInvalidConfiguration;
+}
+
+// ------------------------------------------------------------------------------------------
+// Classic mode, register strip kernel (hs_kernels_classic_strip.hip.h): plan and launch.
+// The shapes that are compiled: R rows per lane with at most classic_strip_max_waves(R) wavefronts (register budget:
+// 24 registers of state per row and about 45 of working set).
+// ------------------------------------------------------------------------------------------
+struct ClassicStripPlan {
+    hsk::ClassicStripGeom g;
+    int R, tiles, lds_bytes;
+};
+
+int classic_strip_max_waves(int R) { return R <= 3 ? 16 : (R <= 5 ? 12 : 8); }
+
+// Is (R, NW) a legal shape for T sweeps on this image?  The row clamps are free only where image row 0 is register row 0
+// of a wavefront and image row H-1 register row R-1 of one (kernel header); a region that meets a border unaligned must
+// own no row within T rows of it.
+bool classic_strip_geom(const hsflow_ctx *c, int T, int R, int NW, hsk::ClassicStripGeom &g)
+{
+    const int W = c->W, H = c->H;
+    const int TH = round_up(T, R), HX = round_up(T, 4);
+    const int CW = 256 - 2 * HX, CH = NW * R - 2 * TH;
+    if (CW < 4 || CH < 1 || CH < TH) return false;
+    const int ty = (H + CH - 1) / CH;
+    if (ty == 1) {
+        if (H % R != 0) return false; // one tile row: top-aligned, so the bottom is aligned only if R divides H
+    } else {
+        const int ylast = H - CH - TH; // last tile row, aligned to the bottom
+        if (ylast < 0 && (-ylast) % R != 0 && H - CH < T) return false; // row 0 inside it, unaligned and too near
+    }
+    g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
+    g.T = T; g.TH = TH; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
+    g.tiles_x = (W + CW - 1) / CW; g.tiles_y = ty;
+    g.ylast = ty == 1 ? -TH : H - CH - TH;
+    g.zero_in = 0;
+    return true;
+}
+
+// Sweeps per launch when the caller leaves it open: the regions are at most 64 rows high (register budget), so the row
+// halo must stay small; 6 is the measured optimum at 1080p and 4K (tools/sweep_classic_strip.py).
+int classic_strip_default_T(const hsflow_ctx *) { return 6; }
+
+bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, ClassicStripPlan &best)
+{
+    double best_cost = 1e300;
+    bool found = false;
+    for (int R = 2; R <= 8; R++) {
+        if (rows && rows != R) continue;
+        for (int NW = 1; NW <= classic_strip_max_waves(R); NW++) {
+            if (threads && threads != NW * 64) continue;
+            hsk::ClassicStripGeom g;
+            if (!classic_strip_geom(c, T, R, NW, g)) continue;
+            const long long tiles = (long long)g.tiles_x * g.tiles_y * c->N;
+            // modelled time: rounds of workgroups x (tile load + T sweeps of R rows on the busiest SIMD + exchange)
+            const int lds = NW * 8192;
+            const int wg_per_cu = std::max(1, std::min(kLdsLimit / lds, classic_strip_max_waves(R) / NW));
+            const double rounds = std::ceil((double)tiles / ((double)kNumCU * wg_per_cu));
+            const double wps = std::max(1.0, wg_per_cu * NW / 4.0);
+            const double halo_frac = std::min(1.0, 2.0 * T / (double)(NW * R));
+            const double sweep = wps * R * 150.0 * 2.5 * (1.0 - 0.45 * halo_frac) + 600.0;
+            const double cost = 12000.0 + rounds * (6000.0 + 40.0 * R * wps + T * sweep);
+            if (cost < best_cost) {
+                best_cost = cost;
+                found = true;
+                best.g = g; best.R = R; best.tiles = (int)tiles; best.lds_bytes = lds;
+            }
+        }
+    }
+    return found;
+}
+
+template <int R, int NTMAX>
+hipError_t launch_classic_strip_t(const hsflow_ctx *c, const ClassicStripPlan &p, bool write_v, const float *ui, const float *vi,
+                                  float *uo, float *vo, float alpha2, bool configure_only)
+{
+    const bool ghost = (p.g.W & 3) != 0;
+    auto kern = write_v ? (ghost ? hsk::k_classic_strip<R, NTMAX, true, true> : hsk::k_classic_strip<R, NTMAX, true, false>)
+                        : (ghost ? hsk::k_classic_strip<R, NTMAX, false, true> : hsk::k_classic_strip<R, NTMAX, false, false>);
+    static bool configured[4][64] = {};
+    const int ki = (write_v ? 2 : 0) + (ghost ? 1 : 0);
+    if (p.lds_bytes > 32 * 1024 && !configured[ki][c->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        configured[ki][c->device & 63] = true;
+    }
+    if (configure_only) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dE[0], c->dE[1], c->dE[2], ui, vi,
+                       uo, vo, p.g, alpha2);
+    return hipGetLastError();
+}
+
+hipError_t launch_classic_strip(const hsflow_ctx *c, const ClassicStripPlan &p, bool write_v, const float *ui, const float *vi,
+                                float *uo, float *vo, float alpha2, bool cfg = false)
+{
+    switch (p.R) {
+    case 2: return launch_classic_strip_t<2, 1024>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 3: return launch_classic_strip_t<3, 1024>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 4: return launch_classic_strip_t<4, 768>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 5: return launch_classic_strip_t<5, 768>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 6: return launch_classic_strip_t<6, 512>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 7: return launch_classic_strip_t<7, 512>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    case 8: return launch_classic_strip_t<8, 512>(c, p, write_v, ui, vi, uo, vo, alpha2, cfg);
+    }
     return hipErrorInvalidConfiguration;
 }
 

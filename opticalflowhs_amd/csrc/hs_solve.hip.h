@@ -3,93 +3,6 @@
 #pragma once
 
 namespace {
-// CLASSIC mode (Kernels.cl semantics, v restored): derivatives once, then max_iter fused
-// average+update sweeps, one launch each.  The reference loop has no other stop rule
-// (HSOpticalFlowOpenCL.cpp:750-751), so only ITER termination is accepted.
-int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
-{
-    if (p.term_type != HSFLOW_TERM_ITER) return fail(c, HSFLOW_E_ARG, "CLASSIC mode supports ITER termination only");
-    if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
-    if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
-    if (p.use_graph || (async && p.profile)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: use_graph / async profiling not supported");
-    const size_t px = (size_t)c->plane * c->N;
-    for (int i = 0; i < 3; i++)
-        if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
-    Profiler prof{c, p.profile != 0};
-    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
-    if (!(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC)) {
-        prof.begin(0);
-        hipLaunchKernelGGL(hsk::k_deriv_classic, grid, block, 0, c->stream, c->dA, c->dB, c->dE[0], c->dE[1], c->dE[2],
-                           c->W, c->H, c->P, c->plane);
-        HS_HIP(c, hipGetLastError());
-        prof.end();
-    }
-    c->coef_valid = true;
-    c->coef_mode = HSFLOW_MODE_CLASSIC;
-    const float a2 = p.alpha * p.alpha; // Kernels.cl:85
-    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
-    int zero = p.use_previous ? 0 : 1;
-    if (zero) c->cur = 0;
-    if (p.kernel != HSFLOW_KERNEL_SIMPLE) {
-        // several sweeps per launch on an LDS tile (k_jacobi_classic_fused)
-        if (p.kernel != HSFLOW_KERNEL_AUTO && p.kernel != HSFLOW_KERNEL_FUSED)
-            return fail(c, HSFLOW_E_ARG, "CLASSIC mode has the simple and the fused (LDS tile) kernels only");
-        // 18 LDS values per plane and group and an IEEE division make a sweep dearer than in CV mode:
-        // the halo pays off up to about 6 sweeps per launch (tools/sweep_classic.py on MI355X)
-        const int T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
-        FusedPlan plan;
-        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, plan))
-            return fail(c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
-        int done = 0, launches = 0;
-        while (done < p.max_iter) {
-            const int chunk = std::min(T, p.max_iter - done);
-            FusedPlan cp = plan;
-            if (chunk != T && !make_plan(c, chunk, p.tile_w, p.tile_h, p.threads, cp))
-                return fail(c, HSFLOW_E_SIZE, "no feasible tile for the tail launch");
-            cp.g.zero_in = zero;
-            const int a = c->cur, b = a ^ 1;
-            prof.begin(1);
-            hipError_t e = launch_classic_fused(c, cp, write_v, c->dU[a], c->dV[a], c->dU[b], c->dV[b], a2);
-            prof.end();
-            HS_HIP(c, e);
-            c->cur = b;
-            zero = 0;
-            done += chunk;
-            launches++;
-        }
-        hsflow_info &i = c->info;
-        i.kernel = HSFLOW_KERNEL_FUSED; i.fuse_steps = T; i.tile_w = plan.g.CW; i.tile_h = plan.g.CH; i.threads = plan.NT;
-        i.groups_per_thread = plan.K; i.tiles = plan.tiles; i.lds_bytes = plan.lds_bytes; i.jacobi_launches = launches;
-        i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
-        if (!async) {
-            HS_HIP(c, hipStreamSynchronize(c->stream));
-            prof.collect();
-        }
-        return HSFLOW_OK;
-    }
-    for (int it = 0; it < p.max_iter; it++) {
-        const int a = c->cur, b = a ^ 1;
-        prof.begin(1);
-        auto kern = zero ? (write_v ? hsk::k_jacobi_classic<true, true> : hsk::k_jacobi_classic<true, false>)
-                         : (write_v ? hsk::k_jacobi_classic<false, true> : hsk::k_jacobi_classic<false, false>);
-        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2], c->dU[a], c->dV[a], c->dU[b], c->dV[b],
-                           c->W, c->H, c->P, c->plane, a2);
-        HS_HIP(c, hipGetLastError());
-        prof.end();
-        c->cur = b;
-        zero = 0;
-    }
-    hsflow_info &i = c->info;
-    i.kernel = HSFLOW_KERNEL_SIMPLE; i.fuse_steps = 1; i.tile_w = i.tile_h = 0; i.threads = 256;
-    i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0; i.jacobi_launches = p.max_iter;
-    i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
-    if (!async) {
-        HS_HIP(c, hipStreamSynchronize(c->stream));
-        prof.collect();
-    }
-    return HSFLOW_OK;
-}
-
 int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async);
 
 // Settles an ITER|EPS solve that hsflow_solve_async left unverified: waits for the stream, looks at the
@@ -186,6 +99,140 @@ int run_captured(hsflow_ctx *c, const GraphKey &key, Configure configure, Enqueu
     HS_HIP(c, hipGraphLaunch(it->second.exec, c->stream));
     c->cur = it->second.cur_after;
     *launches = it->second.launches;
+    return HSFLOW_OK;
+}
+
+// CLASSIC mode (Kernels.cl semantics, v restored): derivatives once, then max_iter fused average+update sweeps --
+// several per launch on a register strip (k_classic_strip) or an LDS tile (k_jacobi_classic_fused), or one per launch
+// (k_jacobi_classic).  The reference loop has no other stop rule (HSOpticalFlowOpenCL.cpp:750-751), so only ITER
+// termination is accepted.  The launch sequence can be one hipGraph (use_graph), like the CV-mode solve.
+int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
+{
+    if (p.term_type != HSFLOW_TERM_ITER) return fail(c, HSFLOW_E_ARG, "CLASSIC mode supports ITER termination only");
+    if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
+    if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
+    if (p.profile && (p.use_graph || async)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: profiling needs a synchronous solve without use_graph");
+    const size_t px = (size_t)c->plane * c->N;
+    for (int i = 0; i < 3; i++)
+        if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
+    Profiler prof{c, p.profile != 0};
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC);
+    const float a2 = p.alpha * p.alpha; // Kernels.cl:85
+    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
+    const bool zero0 = !p.use_previous;
+
+    // which kernel: the register strip wherever the image has an aligned shape for it (classic_strip_geom), else the LDS tile
+    int kernel = p.kernel;
+    if (kernel != HSFLOW_KERNEL_AUTO && kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP)
+        return fail(c, HSFLOW_E_ARG, "CLASSIC mode has the simple, the fused (LDS tile) and the strip kernels only");
+    int T = 1;
+    ClassicStripPlan splan, stail;
+    FusedPlan fplan, ftail;
+    if (kernel == HSFLOW_KERNEL_AUTO || kernel == HSFLOW_KERNEL_STRIP) {
+        T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(classic_strip_default_T(c), p.max_iter);
+        const bool tiles_apply = kernel == HSFLOW_KERNEL_STRIP || (!p.tile_w && !p.tile_h);
+        // (the strip kernels divide with a precomputed reciprocal: legal while alpha^2 is nowhere near the ends of the
+        // exponent range, hs_kernels_classic_strip.hip.h)
+        const bool alpha_ok = a2 >= 0x1p-40f && a2 <= 0x1p40f;
+        bool ok = alpha_ok && tiles_apply && make_classic_strip_plan(c, T, p.strip_rows, p.threads, splan);
+        const int rem = p.max_iter % T;
+        if (ok && rem) ok = make_classic_strip_plan(c, rem, p.strip_rows, p.threads, stail);
+        if (ok) kernel = HSFLOW_KERNEL_STRIP;
+        else if (kernel == HSFLOW_KERNEL_STRIP)
+            return fail(c, alpha_ok ? HSFLOW_E_SIZE : HSFLOW_E_ARG,
+                        alpha_ok ? "CLASSIC mode: no strip shape for this image / fuse_steps / strip_rows / threads"
+                                 : "CLASSIC mode: the strip kernel takes 2^-20 <= alpha <= 2^20");
+        else kernel = HSFLOW_KERNEL_FUSED;
+    }
+    if (kernel == HSFLOW_KERNEL_FUSED) {
+        // 18 LDS values per plane and group and an IEEE division make a sweep dearer than in CV mode:
+        // the halo pays off up to about 6 sweeps per launch (tools/sweep_classic.py on MI355X)
+        T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
+        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, fplan))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
+        const int rem = p.max_iter % T;
+        if (rem && !make_plan(c, rem, p.tile_w, p.tile_h, p.threads, ftail))
+            return fail(c, HSFLOW_E_SIZE, "no feasible tile for the tail launch");
+    }
+    if (kernel == HSFLOW_KERNEL_SIMPLE) T = 1;
+
+    auto enqueue = [&](int *n) -> int {
+        if (do_deriv) {
+            prof.begin(0);
+            hipLaunchKernelGGL(hsk::k_deriv_classic, grid, block, 0, c->stream, c->dA, c->dB, c->dE[0], c->dE[1], c->dE[2],
+                               c->W, c->H, c->P, c->plane);
+            HS_HIP(c, hipGetLastError());
+            prof.end();
+        }
+        int zero = zero0 ? 1 : 0;
+        if (zero) c->cur = 0;
+        int done = 0, launches = 0;
+        while (done < p.max_iter) {
+            const int chunk = std::min(T, p.max_iter - done);
+            const int a = c->cur, b = a ^ 1;
+            prof.begin(1);
+            hipError_t e;
+            if (kernel == HSFLOW_KERNEL_STRIP) {
+                ClassicStripPlan cp = chunk == T ? splan : stail;
+                cp.g.zero_in = zero;
+                e = launch_classic_strip(c, cp, write_v, c->dU[a], c->dV[a], c->dU[b], c->dV[b], a2);
+            } else if (kernel == HSFLOW_KERNEL_FUSED) {
+                FusedPlan cp = chunk == T ? fplan : ftail;
+                cp.g.zero_in = zero;
+                e = launch_classic_fused(c, cp, write_v, c->dU[a], c->dV[a], c->dU[b], c->dV[b], a2);
+            } else {
+                auto kern = zero ? (write_v ? hsk::k_jacobi_classic<true, true> : hsk::k_jacobi_classic<true, false>)
+                                 : (write_v ? hsk::k_jacobi_classic<false, true> : hsk::k_jacobi_classic<false, false>);
+                hipLaunchKernelGGL(kern, grid, block, 0, c->stream, c->dE[0], c->dE[1], c->dE[2], c->dU[a], c->dV[a], c->dU[b], c->dV[b],
+                                   c->W, c->H, c->P, c->plane, a2);
+                e = hipGetLastError();
+            }
+            prof.end();
+            HS_HIP(c, e);
+            c->cur = b;
+            zero = 0;
+            done += chunk;
+            launches++;
+        }
+        *n = launches;
+        return HSFLOW_OK;
+    };
+    auto configure = [&]() -> int { // kernel attributes cannot be set inside a capture
+        if (kernel == HSFLOW_KERNEL_STRIP) {
+            HS_HIP(c, launch_classic_strip(c, splan, write_v, nullptr, nullptr, nullptr, nullptr, a2, true));
+            if (p.max_iter % T) HS_HIP(c, launch_classic_strip(c, stail, write_v, nullptr, nullptr, nullptr, nullptr, a2, true));
+        } else if (kernel == HSFLOW_KERNEL_FUSED) {
+            HS_HIP(c, launch_classic_fused(c, fplan, write_v, nullptr, nullptr, nullptr, nullptr, a2, true));
+            if (p.max_iter % T) HS_HIP(c, launch_classic_fused(c, ftail, write_v, nullptr, nullptr, nullptr, nullptr, a2, true));
+        }
+        return HSFLOW_OK;
+    };
+    hsflow_info &i = c->info;
+    i.kernel = kernel; i.fuse_steps = T;
+    if (kernel == HSFLOW_KERNEL_STRIP) {
+        i.tile_w = splan.g.CW; i.tile_h = splan.g.CH; i.threads = splan.g.NW * 64;
+        i.groups_per_thread = splan.R; i.tiles = splan.tiles; i.lds_bytes = splan.lds_bytes;
+    } else if (kernel == HSFLOW_KERNEL_FUSED) {
+        i.tile_w = fplan.g.CW; i.tile_h = fplan.g.CH; i.threads = fplan.NT;
+        i.groups_per_thread = fplan.K; i.tiles = fplan.tiles; i.lds_bytes = fplan.lds_bytes;
+    } else {
+        i.tile_w = i.tile_h = 0; i.threads = 256; i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0;
+    }
+    int launches = 0, st;
+    if (p.use_graph) {
+        GraphKey key{p.mode, kernel, p.max_iter, T, i.tile_w, i.tile_h, i.threads, i.groups_per_thread, zero0 ? 0 : c->cur,
+                     p.use_previous * 2 + (do_deriv ? 1 : 0), p.alpha};
+        if ((st = run_captured(c, key, configure, enqueue, &launches))) return st;
+    } else if ((st = enqueue(&launches))) return st;
+    c->coef_valid = true;
+    c->coef_mode = HSFLOW_MODE_CLASSIC;
+    i.jacobi_launches = launches;
+    i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
+    if (!async) {
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+        prof.collect();
+    }
     return HSFLOW_OK;
 }
 

@@ -9,6 +9,7 @@
 #include "hs_kernels.hip.h"
 #include "hs_kernels_pre.hip.h"
 #include "hs_kernels_classic.hip.h"
+#include "hs_kernels_classic_strip.hip.h"
 
 #include <algorithm>
 #include <cfloat>

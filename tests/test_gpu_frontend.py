@@ -250,9 +250,9 @@ def test_classic_fused_kernel_equals_single_sweep_kernel(hs, oracle, gpu_ok):
                 assert np.array_equal(u, uo) and np.array_equal(v, vo), (W, H, it, alpha, kw, info)
             info = ctx.solve(mode=hs.MODE_CLASSIC_AS_SHIPPED, alpha=alpha, max_iter=it, term_type=ITER)
             u, v = ctx.flow()
-            assert info["kernel"] == hs.KERNEL_FUSED and np.array_equal(u, us) and not v.any()
+            assert info["kernel"] in (hs.KERNEL_FUSED, hs.KERNEL_STRIP) and np.array_equal(u, us) and not v.any()
             with pytest.raises(hs.HsflowError):
-                ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP)
+                ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_FOLD)
     # a batch of pairs in one context
     W, H, n = 96, 40, 3
     with hs.HSFlow(W, H, n, own_stream=True) as ctx:
@@ -263,6 +263,83 @@ def test_classic_fused_kernel_equals_single_sweep_kernel(hs, oracle, gpu_ok):
         for i, (A, B) in enumerate(pairs):
             u, v = ctx.flow(pair=i)
             uo, vo = oracle.classic_flow(A, B, 4.0, 11)
+            assert np.array_equal(u, uo) and np.array_equal(v, vo), i
+
+
+def test_classic_strip_kernel_bit_exact(hs, oracle, gpu_ok):
+    """The register-strip kernel of the classic mode (k_classic_strip) against oracle/hs_classic_oracle.c, bit for bit:
+    every compiled row count, several tiles in both directions, widths that are no multiple of 4, heights no row count
+    divides (the last tile row is aligned to the bottom border), launches that split the sweeps, flat areas beside
+    moving texture (flow values down to denormals reach the division), warm start, the as-shipped form, several pairs."""
+    rng = np.random.default_rng(11)
+    refused = 0
+    cases = [(600, 300), (333, 131), (258, 64), (1000, 97), (64, 480), (37, 29), (517, 203), (1920, 200)]
+    for case, (W, H) in enumerate(cases):
+        A, B = synth.translating_pair(W, H, seed=160 + case, dx=1.5, dy=-0.5)
+        if case % 2 == 0:  # a static flat area and a static textured one: t = 0 exactly and t -> tiny values
+            B[: H // 3] = A[: H // 3]
+            A[:, : W // 4] = 90
+            B[:, : W // 4] = 90
+        it = int(rng.integers(3, 40))
+        alpha = float(rng.uniform(0.5, 20.0))
+        uo, vo = oracle.classic_flow(A, B, alpha, it)
+        with hs.HSFlow(W, H, own_stream=True) as ctx:
+            ctx.set_frames(A, B)
+            variants = [dict()] + [dict(strip_rows=r) for r in range(2, 9)] + \
+                       [dict(fuse_steps=int(rng.integers(1, 17))), dict(strip_rows=4, threads=256, fuse_steps=3),
+                        dict(strip_rows=8, threads=512, fuse_steps=12), dict(strip_rows=3, threads=1024, fuse_steps=7)]
+            for kw in variants:
+                try:
+                    info = ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP, **kw)
+                except hs.HsflowError:  # no aligned shape for this height with the requested rows / threads
+                    assert kw, (W, H)
+                    refused += 1
+                    continue
+                u, v = ctx.flow()
+                assert info["kernel"] == hs.KERNEL_STRIP and info["iterations_done"] == it
+                assert np.array_equal(u, uo) and np.array_equal(v, vo), (W, H, it, alpha, kw, info,
+                                                                         np.argwhere(u != uo)[:4], np.argwhere(v != vo)[:4])
+            # warm start across two solves, then the as-shipped form (v never written)
+            ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=2, term_type=ITER, kernel=hs.KERNEL_STRIP)
+            ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it - 2, term_type=ITER, kernel=hs.KERNEL_STRIP, use_previous=True,
+                      reuse_derivatives=True)
+            u, v = ctx.flow()
+            assert np.array_equal(u, uo) and np.array_equal(v, vo), (W, H)
+            ctx.solve(mode=hs.MODE_CLASSIC_AS_SHIPPED, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP)
+            u, v = ctx.flow()
+            us, _ = oracle.classic_flow(A, B, alpha, it, update_v=False)
+            assert np.array_equal(u, us) and not v.any()
+    assert refused < 4 * len(cases)
+    # the division: flow that decays into a static textured area runs through every magnitude down to the denormals (a small
+    # alpha makes it fall by orders of magnitude per pixel), so the numerator meets v_div_scale's rescaling and 0 / den
+    W, H = 320, 96
+    A, B = synth.translating_pair(W, H, seed=177, dx=1.5, dy=-0.5)
+    B[:, : W // 2] = A[:, : W // 2]
+    for alpha, it in ((0.02, 60), (0.3, 60)):
+        uo, vo = oracle.classic_flow(A, B, alpha, it)
+        tiny = np.abs(uo[uo != 0])
+        assert tiny.min() < 1e-36 and (uo == 0).any() and tiny.max() > 1e-3, (tiny.min(), tiny.max())
+        with hs.HSFlow(W, H, own_stream=True) as ctx:
+            ctx.set_frames(A, B)
+            for kw in (dict(), dict(strip_rows=6), dict(strip_rows=4), dict(strip_rows=2, fuse_steps=3)):
+                info = ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP, **kw)
+                u, v = ctx.flow()
+                assert np.array_equal(u, uo) and np.array_equal(v, vo), (alpha, kw, info, np.argwhere(u != uo)[:4])
+            with pytest.raises(hs.HsflowError):  # far outside the range the precomputed reciprocal is proven for
+                ctx.solve(mode=hs.MODE_CLASSIC, alpha=1e-9, max_iter=3, term_type=ITER, kernel=hs.KERNEL_STRIP)
+            ctx.solve(mode=hs.MODE_CLASSIC, alpha=1e-9, max_iter=3, term_type=ITER)  # AUTO: the LDS-tile kernel takes it
+            u, v = ctx.flow()
+            uo9, vo9 = oracle.classic_flow(A, B, 1e-9, 3)
+            assert ctx.info()["kernel"] == hs.KERNEL_FUSED and np.array_equal(u, uo9, equal_nan=True) and np.array_equal(v, vo9, equal_nan=True)
+    W, H, n = 300, 160, 3
+    with hs.HSFlow(W, H, n, own_stream=True) as ctx:
+        pairs = [synth.translating_pair(W, H, seed=190 + i) for i in range(n)]
+        for i, (A, B) in enumerate(pairs):
+            ctx.set_frames(A, B, pair=i)
+        ctx.solve(mode=hs.MODE_CLASSIC, alpha=4.0, max_iter=13, term_type=ITER, kernel=hs.KERNEL_STRIP)
+        for i, (A, B) in enumerate(pairs):
+            u, v = ctx.flow(pair=i)
+            uo, vo = oracle.classic_flow(A, B, 4.0, 13)
             assert np.array_equal(u, uo) and np.array_equal(v, vo), i
 
 
