@@ -57,7 +57,8 @@ struct hsflow_ctx {
     bool own_stream = false;
     uint8_t *dA = nullptr, *dB = nullptr;
     uint32_t *dCoef = nullptr;
-    float *dE[3] = {nullptr, nullptr, nullptr}; // CLASSIC mode: Ex, Ey, Et planes (allocated on first use)
+    float *dE[3] = {nullptr, nullptr, nullptr}; // CLASSIC mode: Ex, Ey, Et planes for the kernels that read planes (allocated on first use)
+    bool dE_valid = false;       // ... and whether they hold the current derivatives (dCoef always does, packed)
     int coef_mode = -1;          // discretisation the current derivatives belong to
     float *dU[2] = {nullptr, nullptr}, *dV[2] = {nullptr, nullptr};
     unsigned long long *dStamps = nullptr; // diagnostic phase stamps (HSFLOW_DEBUG_STAMPS), else NULL

@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256) void k_deriv_cv(const uint8_t *__restrict__ A,
 }
 
 // Decode the packed plane to three fp32 planes (hsflow_get_derivatives; not on the hot path).
+__device__ __forceinline__ void unpack_classic_deriv(uint32_t w, float &ex, float &ey, float &et); // hs_kernels_classic.hip.h
+template <bool CLASSIC>
 __global__ __launch_bounds__(256) void k_unpack_deriv(const uint32_t *__restrict__ coef,
                                                       float *__restrict__ dx,
                                                       float *__restrict__ dy,
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(256) void k_unpack_deriv(const uint32_t *__restrict
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
     float Ix, Iy, It;
-    unpack_deriv(coef[(long long)y * P + x], Ix, Iy, It);
+    if (CLASSIC) unpack_classic_deriv(coef[(long long)y * P + x], Ix, Iy, It);
+    else unpack_deriv(coef[(long long)y * P + x], Ix, Iy, It);
     dx[(long long)y * W + x] = Ix;
     dy[(long long)y * W + x] = Iy;
     dt[(long long)y * W + x] = It;

@@ -1,6 +1,6 @@
 // hs_kernels_classic.hip.h -- the reference's own OpenCL discretisation ("-cl" route), re-written
 // for gfx950 with the v update restored:
-//   ComputeDerivativesKernel   OpticalFlowHS/Kernels.cl:13-39   2x2x2 cube differences over both frames
+//   ComputeDerivativesKernel   OpticalFlowHS/Kernels.cl:13-39   2x2x2 cube differences over both frames (k_deriv_classic_packed)
 //   u_v_avgKernel              OpticalFlowHS/Kernels.cl:43-68   1/6 (W,E,N,S) + 1/12 (corners)
 //   u_v_updateKernel           OpticalFlowHS/Kernels.cl:71-90   alpha^2 regulariser; writes u AND v here
 // The two per-iteration kernels of the reference are fused into one pass (u_avg / v_avg never touch
@@ -15,9 +15,25 @@
 
 namespace hsk {
 
-__global__ __launch_bounds__(256) void k_deriv_classic(const uint8_t *__restrict__ A, const uint8_t *__restrict__ B,
-                                                       float *__restrict__ Ex, float *__restrict__ Ey,
-                                                       float *__restrict__ Et, int W, int H, int P, long long plane)
+// The three derivatives of a pixel in ONE 32-bit word (what the strip kernel loads: 4 instead of 12 bytes per pixel and
+// launch).  4*Ex, 4*Ey, 4*Et are integers in [-1020, 1020] (sums of four differences of 8-bit values), and each pixel
+// of the 2x2x2 cube enters each of them exactly once, so all three have the SAME parity: 11 bits of 4*Ex, then 4*Ey and
+// 4*Et without their lowest bit, 10 bits each.  0.25f * (float)n reproduces Kernels.cl:25-38's value bit for bit (the
+// sums there are exact in fp32, a zero sum is +0).
+__device__ __forceinline__ uint32_t pack_classic_deriv(float sx, float sy, float st) // the sums, before the 1/4
+{
+    const int ex4 = (int)sx, ey4 = (int)sy, et4 = (int)st;
+    return ((uint32_t)ex4 & 0x7FFu) | (((uint32_t)(ey4 >> 1) & 0x3FFu) << 11) | (((uint32_t)(et4 >> 1) & 0x3FFu) << 21);
+}
+__device__ __forceinline__ void unpack_classic_deriv(uint32_t w, float &ex, float &ey, float &et)
+{
+    const int ex4 = (int)(w << 21) >> 21, par = ex4 & 1;
+    const int ey4 = (((int)(w << 11) >> 22) << 1) | par, et4 = (((int)(w << 1) >> 22) << 1) | par;
+    ex = 0.25f * (float)ex4; ey = 0.25f * (float)ey4; et = 0.25f * (float)et4;
+}
+
+__global__ __launch_bounds__(256) void k_deriv_classic_packed(const uint8_t *__restrict__ A, const uint8_t *__restrict__ B,
+                                                              uint32_t *__restrict__ coef, int W, int H, int P, long long plane)
 {
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
@@ -33,16 +49,33 @@ __global__ __launch_bounds__(256) void k_deriv_classic(const uint8_t *__restrict
         ra0[k] = (float)a0[xc]; ra1[k] = (float)a1[xc];
         rb0[k] = (float)b0[xc]; rb1[k] = (float)b1[xc];
     }
-    float ex[4], ey[4], et[4];
+    uint32_t wd[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float a00 = ra0[k], a10 = ra0[k + 1], a01 = ra1[k], a11 = ra1[k + 1];
         const float b00 = rb0[k], b10 = rb0[k + 1], b01 = rb1[k], b11 = rb1[k + 1];
-        ex[k] = 0.25f * (a10 - a00 + a11 - a01 + b10 - b00 + b11 - b01);
-        ey[k] = 0.25f * (a01 - a00 + a11 - a10 + b01 - b00 + b11 - b10);
-        et[k] = 0.25f * (b00 - a00 + b10 - a10 + b01 - a01 + b11 - a11);
+        wd[k] = pack_classic_deriv(a10 - a00 + a11 - a01 + b10 - b00 + b11 - b01, a01 - a00 + a11 - a10 + b01 - b00 + b11 - b10,
+                                   b00 - a00 + b10 - a10 + b01 - a01 + b11 - a11);
     }
-    const long long o = base + (long long)y * P + x0;
+    *(uint4 *)(coef + base + (long long)y * P + x0) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
+
+// The packed plane as three fp32 planes of the same pitch: for the LDS-tile and the one-sweep kernels below (which
+// read planes) and for hsflow_get_derivatives.
+__global__ __launch_bounds__(256) void k_unpack_classic_deriv(const uint32_t *__restrict__ coef, float *__restrict__ Ex,
+                                                              float *__restrict__ Ey, float *__restrict__ Et, int W, int H,
+                                                              int P, long long plane)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const long long o = (long long)blockIdx.z * plane + (long long)y * P + x0;
+    const uint4 w = *(const uint4 *)(coef + o);
+    float ex[4], ey[4], et[4];
+    unpack_classic_deriv(w.x, ex[0], ey[0], et[0]);
+    unpack_classic_deriv(w.y, ex[1], ey[1], et[1]);
+    unpack_classic_deriv(w.z, ex[2], ey[2], et[2]);
+    unpack_classic_deriv(w.w, ex[3], ey[3], et[3]);
     *(float4 *)(Ex + o) = make_float4(ex[0], ex[1], ex[2], ex[3]);
     *(float4 *)(Ey + o) = make_float4(ey[0], ey[1], ey[2], ey[3]);
     *(float4 *)(Et + o) = make_float4(et[0], et[1], et[2], et[3]);

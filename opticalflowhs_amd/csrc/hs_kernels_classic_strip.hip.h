@@ -1,6 +1,6 @@
 // hs_kernels_classic_strip.hip.h -- the classic mode (Kernels.cl semantics, hs_kernels_classic.hip.h) as a REGISTER STRIP
 // kernel: T sweeps per launch on a 256-column x NW*R-row region whose rows live in VGPRs (a lane owns 4 consecutive
-// columns of R rows: u, v, Ex, Ey, Et and the denominator), left / right neighbours by DPP, the rows of the
+// columns of R rows: u, v, Ex, Ey, Et -- loaded as one packed word per pixel, pack_classic_deriv -- and the denominator), left / right neighbours by DPP, the rows of the
 // wavefronts above and below through one LDS exchange and one barrier per sweep -- the skeleton of k_jacobi_strip.
 //   u_v_avgKernel      OpticalFlowHS/Kernels.cl:43-68   ((L+R)+U)+D and ((UL+UR)+DL)+DR, 1/6 and 1/12
 //   u_v_updateKernel   OpticalFlowHS/Kernels.cl:71-90   t = (Ex*ua + Ey*va + Et) / (alpha^2 + Ex^2 + Ey^2)
@@ -68,8 +68,7 @@ struct CWin { float l, c0, c1, c2, c3, r; }; // columns x0-1 .. x0+4 of one row 
 struct CH4 { float h0, h1, h2, h3; };         // L + R of the four pixels
 
 template <int R, int NTMAX, bool WRITE_V, bool GHOST> // GHOST: W % 4 != 0 (pixels right of column W-1 inside a lane)
-__global__ __launch_bounds__(NTMAX) void k_classic_strip(const float *__restrict__ Ex, const float *__restrict__ Ey,
-                                                         const float *__restrict__ Et, const float *__restrict__ u_in,
+__global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restrict__ coef, const float *__restrict__ u_in,
                                                          const float *__restrict__ v_in, float *__restrict__ u_out,
                                                          float *__restrict__ v_out, const ClassicStripGeom g,
                                                          const float alpha2)
@@ -99,7 +98,8 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const float *__restrict
     const bool xin = x0 >= 0 && x0 + 3 < g.W;
     const bool slow = GHOST && !xin && ((x0 >= 0 && x0 < g.W) || g.W < 4);
     const int xg = g.W < 4 ? 0 : clampi(x0, 0, (g.W - 4) & ~3);
-    float4 lu[R], lv[R], le[R], lf[R], lt[R];
+    float4 lu[R], lv[R];
+    uint4 lc[R]; // packed derivatives (pack_classic_deriv)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const long long row = base + (long long)clampi(y0 + r, 0, g.H - 1) * g.P;
@@ -108,9 +108,7 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const float *__restrict
             lu[r] = *(const float4 *)(u_in + row + xg);
             lv[r] = *(const float4 *)(v_in + row + xg);
         }
-        le[r] = *(const float4 *)(Ex + row + xg);
-        lf[r] = *(const float4 *)(Ey + row + xg);
-        lt[r] = *(const float4 *)(Et + row + xg);
+        lc[r] = *(const uint4 *)(coef + row + xg);
     }
     if (GHOST && __builtin_amdgcn_ballot_w64(slow) != 0) { // Tex2D clamp (Kernels.cl:2-9): columns right of W-1 read column W-1
         if (slow) {
@@ -123,9 +121,7 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const float *__restrict
                     lu[r] = make_float4(u_in[row + xa], u_in[row + xb], u_in[row + xc], u_in[row + xd]);
                     lv[r] = make_float4(v_in[row + xa], v_in[row + xb], v_in[row + xc], v_in[row + xd]);
                 }
-                le[r] = make_float4(Ex[row + xa], Ex[row + xb], Ex[row + xc], Ex[row + xd]);
-                lf[r] = make_float4(Ey[row + xa], Ey[row + xb], Ey[row + xc], Ey[row + xd]);
-                lt[r] = make_float4(Et[row + xa], Et[row + xb], Et[row + xc], Et[row + xd]);
+                lc[r] = make_uint4(coef[row + xa], coef[row + xb], coef[row + xc], coef[row + xd]);
             }
         }
     }
@@ -136,9 +132,10 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const float *__restrict
     for (int r = 0; r < R; r++) {
         u[r][0] = lu[r].x; u[r][1] = lu[r].y; u[r][2] = lu[r].z; u[r][3] = lu[r].w;
         v[r][0] = lv[r].x; v[r][1] = lv[r].y; v[r][2] = lv[r].z; v[r][3] = lv[r].w;
-        cEx[r][0] = le[r].x; cEx[r][1] = le[r].y; cEx[r][2] = le[r].z; cEx[r][3] = le[r].w;
-        cEy[r][0] = lf[r].x; cEy[r][1] = lf[r].y; cEy[r][2] = lf[r].z; cEy[r][3] = lf[r].w;
-        cEt[r][0] = lt[r].x; cEt[r][1] = lt[r].y; cEt[r][2] = lt[r].z; cEt[r][3] = lt[r].w;
+        unpack_classic_deriv(lc[r].x, cEx[r][0], cEy[r][0], cEt[r][0]);
+        unpack_classic_deriv(lc[r].y, cEx[r][1], cEy[r][1], cEt[r][1]);
+        unpack_classic_deriv(lc[r].z, cEx[r][2], cEy[r][2], cEt[r][2]);
+        unpack_classic_deriv(lc[r].w, cEx[r][3], cEy[r][3], cEt[r][3]);
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             cDn[r][p] = alpha2 + cEx[r][p] * cEx[r][p] + cEy[r][p] * cEy[r][p]; // Kernels.cl:85

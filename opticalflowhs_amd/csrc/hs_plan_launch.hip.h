@@ -211,8 +211,7 @@ hipError_t launch_classic_strip_t(const hsflow_ctx *c, const ClassicStripPlan &p
         configured[ki][c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dE[0], c->dE[1], c->dE[2], ui, vi,
-                       uo, vo, p.g, alpha2);
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi, uo, vo, p.g, alpha2);
     return hipGetLastError();
 }
 

@@ -112,9 +112,6 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
     if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
     if (p.profile && (p.use_graph || async)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: profiling needs a synchronous solve without use_graph");
-    const size_t px = (size_t)c->plane * c->N;
-    for (int i = 0; i < 3; i++)
-        if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
     Profiler prof{c, p.profile != 0};
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
     const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC);
@@ -157,13 +154,26 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     }
     if (kernel == HSFLOW_KERNEL_SIMPLE) T = 1;
 
+    // The derivatives live as one packed word per pixel (k_deriv_classic_packed; what the strip kernel loads); the
+    // LDS-tile and the one-sweep kernels read three fp32 planes, unpacked once per derivative pass when they run.
+    const bool need_planes = kernel != HSFLOW_KERNEL_STRIP;
+    if (need_planes) {
+        const size_t px = (size_t)c->plane * c->N;
+        for (int i = 0; i < 3; i++)
+            if (!c->dE[i]) HS_HIP(c, hipMalloc((void **)&c->dE[i], px * sizeof(float)));
+    }
+    const bool do_unpack = need_planes && (do_deriv || !c->dE_valid);
     auto enqueue = [&](int *n) -> int {
         if (do_deriv) {
             prof.begin(0);
-            hipLaunchKernelGGL(hsk::k_deriv_classic, grid, block, 0, c->stream, c->dA, c->dB, c->dE[0], c->dE[1], c->dE[2],
-                               c->W, c->H, c->P, c->plane);
+            hipLaunchKernelGGL(hsk::k_deriv_classic_packed, grid, block, 0, c->stream, c->dA, c->dB, c->dCoef, c->W, c->H, c->P, c->plane);
             HS_HIP(c, hipGetLastError());
             prof.end();
+        }
+        if (do_unpack) {
+            hipLaunchKernelGGL(hsk::k_unpack_classic_deriv, grid, block, 0, c->stream, c->dCoef, c->dE[0], c->dE[1], c->dE[2],
+                               c->W, c->H, c->P, c->plane);
+            HS_HIP(c, hipGetLastError());
         }
         int zero = zero0 ? 1 : 0;
         if (zero) c->cur = 0;
@@ -222,11 +232,12 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     int launches = 0, st;
     if (p.use_graph) {
         GraphKey key{p.mode, kernel, p.max_iter, T, i.tile_w, i.tile_h, i.threads, i.groups_per_thread, zero0 ? 0 : c->cur,
-                     p.use_previous * 2 + (do_deriv ? 1 : 0), p.alpha};
+                     p.use_previous * 2 + (do_deriv ? 1 : 0) + (do_unpack ? 4 : 0), p.alpha};
         if ((st = run_captured(c, key, configure, enqueue, &launches))) return st;
     } else if ((st = enqueue(&launches))) return st;
     c->coef_valid = true;
     c->coef_mode = HSFLOW_MODE_CLASSIC;
+    c->dE_valid = do_unpack || (c->dE_valid && !do_deriv);
     i.jacobi_launches = launches;
     i.iterations_done = p.max_iter; i.last_eps = 0.f; i.deriv_ms = i.jacobi_ms = i.solve_ms = 0.f;
     if (!async) {

@@ -444,16 +444,13 @@ int hsflow_get_derivatives(hsflow_ctx *c, int pair, float *dx, float *dy, float 
         HS_HIP(c, hipMalloc(&c->dScratch, need));
         c->scratch_bytes = need;
     }
-    if (c->coef_mode == HSFLOW_MODE_CLASSIC) { // planar fp32 already: strided copies
-        HS_HIP(c, hipStreamSynchronize(c->stream));
-        float *dst[3] = {dx, dy, dt};
-        for (int i = 0; i < 3; i++)
-            HS_HIP(c, hipMemcpy2D(dst[i], stride, c->dE[i] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
-        return HSFLOW_OK;
-    }
     float *sx = (float *)c->dScratch, *sy = sx + (size_t)c->W * c->H, *stt = sy + (size_t)c->W * c->H;
-    hipLaunchKernelGGL(hsk::k_unpack_deriv, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,
-                       c->dCoef + pair * c->plane, sx, sy, stt, c->W, c->H, c->P);
+    if (c->coef_mode == HSFLOW_MODE_CLASSIC) // (each mode packs its derivatives its own way)
+        hipLaunchKernelGGL(hsk::k_unpack_deriv<true>, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,
+                           c->dCoef + pair * c->plane, sx, sy, stt, c->W, c->H, c->P);
+    else
+        hipLaunchKernelGGL(hsk::k_unpack_deriv<false>, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,
+                           c->dCoef + pair * c->plane, sx, sy, stt, c->W, c->H, c->P);
     HS_HIP(c, hipGetLastError());
     HS_HIP(c, hipStreamSynchronize(c->stream));
     HS_HIP(c, hipMemcpy2D(dx, stride, sx, rowb, rowb, c->H, hipMemcpyDeviceToHost));
