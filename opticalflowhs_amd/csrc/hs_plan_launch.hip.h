@@ -162,11 +162,26 @@ bool classic_strip_geom(const hsflow_ctx *c, int T, int R, int NW, hsk::ClassicS
     return true;
 }
 
-// Sweeps per launch when the caller leaves it open: the regions are at most 64 rows high (register budget), so the row
-// halo must stay small; 6 is the measured optimum at 1080p and 4K (tools/sweep_classic_strip.py).
-int classic_strip_default_T(const hsflow_ctx *) { return 6; }
+// Modelled time of one launch in microseconds, fitted to tools/sweep_classic_strip.py on MI355X at 480p, 720p, 1080p and
+// 4K (profiles/r02_sweep_classic_strip.txt; within 10 % there): a launch gap, the planes through the cache hierarchy
+// (20 bytes per pixel at ~12 TB/s), then per round of workgroups the rows the busiest SIMD holds, each loaded and
+// unpacked once and swept T times (halo wavefronts drop out one by one, fewer resident wavefronts hide less latency).
+double classic_strip_launch_us(const hsflow_ctx *c, const hsk::ClassicStripGeom &g, int R, long long tiles, int *wg_per_cu_out = nullptr)
+{
+    const int NW = g.NW, lds = NW * 8192;
+    const int wg_per_cu = std::max(1, std::min(kLdsLimit / lds, classic_strip_max_waves(R) / NW));
+    if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
+    const double rounds = std::ceil((double)tiles / ((double)kNumCU * wg_per_cu));
+    const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // workgroups sharing a CU
+    const double wps = (double)((NW + 3) / 4) * (double)conc;                              // wavefronts on the busiest SIMD
+    const double rps = wps * R;                                                              // ... and their rows
+    const double few = wps >= 3.5 ? 1.0 : (wps >= 2.5 ? 1.1 : (wps >= 1.5 ? 1.2 : 1.5));
+    const double halo_frac = std::min(1.0, 2.0 * g.TH / (double)(NW * R));
+    const double bytes_us = (double)g.W * g.H * c->N * 20.0 / 12e6;
+    return 2.0 + bytes_us + rounds * rps * (0.32 + 0.22 * few * g.T * (1.0 - 0.25 * halo_frac));
+}
 
-bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, ClassicStripPlan &best)
+bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, ClassicStripPlan &best, double *cost_out = nullptr)
 {
     double best_cost = 1e300;
     bool found = false;
@@ -177,22 +192,34 @@ bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, 
             hsk::ClassicStripGeom g;
             if (!classic_strip_geom(c, T, R, NW, g)) continue;
             const long long tiles = (long long)g.tiles_x * g.tiles_y * c->N;
-            // modelled time: rounds of workgroups x (tile load + T sweeps of R rows on the busiest SIMD + exchange)
-            const int lds = NW * 8192;
-            const int wg_per_cu = std::max(1, std::min(kLdsLimit / lds, classic_strip_max_waves(R) / NW));
-            const double rounds = std::ceil((double)tiles / ((double)kNumCU * wg_per_cu));
-            const double wps = std::max(1.0, wg_per_cu * NW / 4.0);
-            const double halo_frac = std::min(1.0, 2.0 * T / (double)(NW * R));
-            const double sweep = wps * R * 150.0 * 2.5 * (1.0 - 0.45 * halo_frac) + 600.0;
-            const double cost = 12000.0 + rounds * (6000.0 + 40.0 * R * wps + T * sweep);
+            const double cost = classic_strip_launch_us(c, g, R, tiles);
             if (cost < best_cost) {
                 best_cost = cost;
                 found = true;
-                best.g = g; best.R = R; best.tiles = (int)tiles; best.lds_bytes = lds;
+                best.g = g; best.R = R; best.tiles = (int)tiles; best.lds_bytes = NW * 8192;
             }
         }
     }
+    if (cost_out) *cost_out = best_cost;
     return found;
+}
+
+// Sweeps per launch when the caller leaves them open: minimise the modelled time of the whole solve (full launches of T
+// plus one tail launch).  The regions are at most 64 rows high (register budget), so the answer is small: 6 at 1080p.
+int pick_classic_strip_T(const hsflow_ctx *c, int iters, int rows, int threads)
+{
+    double best = 1e300;
+    int bestT = 0;
+    for (int T = 1; T <= std::min(iters, 16); T++) {
+        ClassicStripPlan sp;
+        double cfull = 0, ctail = 0;
+        if (!make_classic_strip_plan(c, T, rows, threads, sp, &cfull)) continue;
+        const int rem = iters % T;
+        if (rem && !make_classic_strip_plan(c, rem, rows, threads, sp, &ctail)) continue;
+        const double total = (iters / T) * cfull + (rem ? ctail : 0.0);
+        if (total < best) { best = total; bestT = T; }
+    }
+    return bestT;
 }
 
 template <int R, int NTMAX>

@@ -127,8 +127,9 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     ClassicStripPlan splan, stail;
     FusedPlan fplan, ftail;
     if (kernel == HSFLOW_KERNEL_AUTO || kernel == HSFLOW_KERNEL_STRIP) {
-        T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(classic_strip_default_T(c), p.max_iter);
-        const bool tiles_apply = kernel == HSFLOW_KERNEL_STRIP || (!p.tile_w && !p.tile_h);
+        T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : pick_classic_strip_T(c, p.max_iter, p.strip_rows, p.threads);
+        const bool tiles_apply = T > 0 && (kernel == HSFLOW_KERNEL_STRIP || (!p.tile_w && !p.tile_h));
+        if (T <= 0) T = 1;
         // (the strip kernels divide with a precomputed reciprocal: legal while alpha^2 is nowhere near the ends of the
         // exponent range, hs_kernels_classic_strip.hip.h)
         const bool alpha_ok = a2 >= 0x1p-40f && a2 <= 0x1p40f;
