@@ -106,26 +106,25 @@ int run_captured(hsflow_ctx *c, const GraphKey &key, Configure configure, Enqueu
 // several per launch on a register strip (k_classic_strip) or an LDS tile (k_jacobi_classic_fused), or one per launch
 // (k_jacobi_classic).  The reference loop has no other stop rule (HSOpticalFlowOpenCL.cpp:750-751), so only ITER
 // termination is accepted.  The launch sequence can be one hipGraph (use_graph), like the CV-mode solve.
-int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
+struct ClassicSetup {
+    int kernel, T; // kernel actually used (AUTO resolved), sweeps per full launch
+    ClassicStripPlan splan, stail;
+    FusedPlan fplan, ftail;
+};
+
+// Checks the parameters, picks the kernel and the launch plans and writes the plan into c->info (hsflow_plan_query
+// stops here; no device is touched).
+int prepare_classic(hsflow_ctx *c, const hsflow_params &p, ClassicSetup &S)
 {
     if (p.term_type != HSFLOW_TERM_ITER) return fail(c, HSFLOW_E_ARG, "CLASSIC mode supports ITER termination only");
     if (p.max_iter <= 0) return fail(c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
     if (!(p.alpha > 0.f) || !std::isfinite(p.alpha)) return fail(c, HSFLOW_E_ARG, "alpha must be positive");
-    if (p.profile && (p.use_graph || async)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: profiling needs a synchronous solve without use_graph");
-    Profiler prof{c, p.profile != 0};
-    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
-    const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC);
     const float a2 = p.alpha * p.alpha; // Kernels.cl:85
-    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
-    const bool zero0 = !p.use_previous;
-
     // which kernel: the register strip wherever the image has an aligned shape for it (classic_strip_geom), else the LDS tile
     int kernel = p.kernel;
     if (kernel != HSFLOW_KERNEL_AUTO && kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP)
         return fail(c, HSFLOW_E_ARG, "CLASSIC mode has the simple, the fused (LDS tile) and the strip kernels only");
     int T = 1;
-    ClassicStripPlan splan, stail;
-    FusedPlan fplan, ftail;
     if (kernel == HSFLOW_KERNEL_AUTO || kernel == HSFLOW_KERNEL_STRIP) {
         T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : pick_classic_strip_T(c, p.max_iter, p.strip_rows, p.threads);
         const bool tiles_apply = T > 0 && (kernel == HSFLOW_KERNEL_STRIP || (!p.tile_w && !p.tile_h));
@@ -133,9 +132,9 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
         // (the strip kernels divide with a precomputed reciprocal: legal while alpha^2 is nowhere near the ends of the
         // exponent range, hs_kernels_classic_strip.hip.h)
         const bool alpha_ok = a2 >= 0x1p-40f && a2 <= 0x1p40f;
-        bool ok = alpha_ok && tiles_apply && make_classic_strip_plan(c, T, p.strip_rows, p.threads, splan);
+        bool ok = alpha_ok && tiles_apply && make_classic_strip_plan(c, T, p.strip_rows, p.threads, S.splan);
         const int rem = p.max_iter % T;
-        if (ok && rem) ok = make_classic_strip_plan(c, rem, p.strip_rows, p.threads, stail);
+        if (ok && rem) ok = make_classic_strip_plan(c, rem, p.strip_rows, p.threads, S.stail);
         if (ok) kernel = HSFLOW_KERNEL_STRIP;
         else if (kernel == HSFLOW_KERNEL_STRIP)
             return fail(c, alpha_ok ? HSFLOW_E_SIZE : HSFLOW_E_ARG,
@@ -147,14 +146,45 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
         // 18 LDS values per plane and group and an IEEE division make a sweep dearer than in CV mode:
         // the halo pays off up to about 6 sweeps per launch (tools/sweep_classic.py on MI355X)
         T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
-        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, fplan))
+        if (!make_plan(c, T, p.tile_w, p.tile_h, p.threads, S.fplan))
             return fail(c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
         const int rem = p.max_iter % T;
-        if (rem && !make_plan(c, rem, p.tile_w, p.tile_h, p.threads, ftail))
+        if (rem && !make_plan(c, rem, p.tile_w, p.tile_h, p.threads, S.ftail))
             return fail(c, HSFLOW_E_SIZE, "no feasible tile for the tail launch");
     }
     if (kernel == HSFLOW_KERNEL_SIMPLE) T = 1;
+    S.kernel = kernel;
+    S.T = T;
+    hsflow_info &i = c->info;
+    i.kernel = kernel; i.fuse_steps = T;
+    if (kernel == HSFLOW_KERNEL_STRIP) {
+        i.tile_w = S.splan.g.CW; i.tile_h = S.splan.g.CH; i.threads = S.splan.g.NW * 64;
+        i.groups_per_thread = S.splan.R; i.tiles = S.splan.tiles; i.lds_bytes = S.splan.lds_bytes;
+    } else if (kernel == HSFLOW_KERNEL_FUSED) {
+        i.tile_w = S.fplan.g.CW; i.tile_h = S.fplan.g.CH; i.threads = S.fplan.NT;
+        i.groups_per_thread = S.fplan.K; i.tiles = S.fplan.tiles; i.lds_bytes = S.fplan.lds_bytes;
+    } else {
+        i.tile_w = i.tile_h = 0; i.threads = 256; i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0;
+    }
+    i.jacobi_launches = (p.max_iter + T - 1) / T;
+    return HSFLOW_OK;
+}
 
+int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
+{
+    ClassicSetup S;
+    int st = prepare_classic(c, p, S);
+    if (st) return st;
+    if (p.profile && (p.use_graph || async)) return fail(c, HSFLOW_E_ARG, "CLASSIC mode: profiling needs a synchronous solve without use_graph");
+    Profiler prof{c, p.profile != 0};
+    const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
+    const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CLASSIC);
+    const float a2 = p.alpha * p.alpha; // Kernels.cl:85
+    const bool write_v = p.mode != HSFLOW_MODE_CLASSIC_AS_SHIPPED;
+    const bool zero0 = !p.use_previous;
+    const int kernel = S.kernel, T = S.T;
+    const ClassicStripPlan &splan = S.splan, &stail = S.stail;
+    const FusedPlan &fplan = S.fplan, &ftail = S.ftail;
     // The derivatives live as one packed word per pixel (k_deriv_classic_packed; what the strip kernel loads); the
     // LDS-tile and the one-sweep kernels read three fp32 planes, unpacked once per derivative pass when they run.
     const bool need_planes = kernel != HSFLOW_KERNEL_STRIP;
@@ -220,17 +250,7 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
         return HSFLOW_OK;
     };
     hsflow_info &i = c->info;
-    i.kernel = kernel; i.fuse_steps = T;
-    if (kernel == HSFLOW_KERNEL_STRIP) {
-        i.tile_w = splan.g.CW; i.tile_h = splan.g.CH; i.threads = splan.g.NW * 64;
-        i.groups_per_thread = splan.R; i.tiles = splan.tiles; i.lds_bytes = splan.lds_bytes;
-    } else if (kernel == HSFLOW_KERNEL_FUSED) {
-        i.tile_w = fplan.g.CW; i.tile_h = fplan.g.CH; i.threads = fplan.NT;
-        i.groups_per_thread = fplan.K; i.tiles = fplan.tiles; i.lds_bytes = fplan.lds_bytes;
-    } else {
-        i.tile_w = i.tile_h = 0; i.threads = 256; i.groups_per_thread = 1; i.tiles = 0; i.lds_bytes = 0;
-    }
-    int launches = 0, st;
+    int launches = 0;
     if (p.use_graph) {
         GraphKey key{p.mode, kernel, p.max_iter, T, i.tile_w, i.tile_h, i.threads, i.groups_per_thread, zero0 ? 0 : c->cur,
                      p.use_previous * 2 + (do_deriv ? 1 : 0) + (do_unpack ? 4 : 0), p.alpha};

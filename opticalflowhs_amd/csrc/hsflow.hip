@@ -549,18 +549,8 @@ int hsflow_plan_query(int width, int height, int n_pairs, const hsflow_params *p
             c.info.jacobi_launches = S.multi ? (int)((b + S.T - 1) / S.T) : (int)b;
         }
     } else if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) {
-        if (p.max_iter <= 0) st = fail(&c, HSFLOW_E_NOTERM, "ITER termination with max_iter <= 0 would never stop");
-        else if (p.kernel == HSFLOW_KERNEL_SIMPLE) { c.info.kernel = HSFLOW_KERNEL_SIMPLE; c.info.fuse_steps = 1; c.info.threads = 256; c.info.jacobi_launches = p.max_iter; }
-        else {
-            const int T = p.fuse_steps > 0 ? std::min(p.fuse_steps, kMaxFuse) : std::min(6, p.max_iter);
-            FusedPlan plan;
-            if (!make_plan(&c, T, p.tile_w, p.tile_h, p.threads, plan)) st = fail(&c, HSFLOW_E_SIZE, "no feasible tile for the requested fuse_steps / tile / threads");
-            else {
-                hsflow_info &i = c.info;
-                i.kernel = HSFLOW_KERNEL_FUSED; i.fuse_steps = T; i.tile_w = plan.g.CW; i.tile_h = plan.g.CH; i.threads = plan.NT;
-                i.groups_per_thread = plan.K; i.tiles = plan.tiles; i.lds_bytes = plan.lds_bytes; i.jacobi_launches = (p.max_iter + T - 1) / T;
-            }
-        }
+        ClassicSetup S;
+        st = prepare_classic(&c, p, S);
     } else st = fail(&c, HSFLOW_E_ARG, "unknown mode");
     if (st) { g_create_error = c.err; return st; }
     *out = c.info;

@@ -72,7 +72,16 @@ def test_planner_known_configs_and_refusals(hs):
     c3 = hs.plan_query(3840, 2160, lam=1.0, max_iter=200, term_type=hs.TERM_ITER)           # C3
     assert c3["kernel"] == hs.KERNEL_STRIP
     cl = hs.plan_query(1920, 1080, mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=100, term_type=hs.TERM_ITER)
-    assert cl["kernel"] == hs.KERNEL_FUSED and cl["fuse_steps"] == 6 and cl["jacobi_launches"] == 17
+    assert cl["kernel"] == hs.KERNEL_STRIP and cl["tiles"] <= 256 and cl["jacobi_launches"] <= 17   # register strip, one round
+    cf = hs.plan_query(1920, 1080, mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=100, term_type=hs.TERM_ITER, kernel=hs.KERNEL_FUSED)
+    assert cf["kernel"] == hs.KERNEL_FUSED and cf["fuse_steps"] == 6 and cf["jacobi_launches"] == 17
+    # no strip shape (more sweeps per launch than a region has halo rows for) or an alpha outside the range of the strip
+    # kernel's division: AUTO falls back to the LDS tile, an explicit request is refused
+    for kw in (dict(width=200, height=37, alpha=15.0, fuse_steps=30), dict(width=1920, height=1080, alpha=1e-9)):
+        w, h = kw.pop("width"), kw.pop("height")
+        assert hs.plan_query(w, h, mode=hs.MODE_CLASSIC, max_iter=20, term_type=hs.TERM_ITER, **kw)["kernel"] == hs.KERNEL_FUSED
+        with pytest.raises(hs.HsflowError):
+            hs.plan_query(w, h, mode=hs.MODE_CLASSIC, max_iter=20, term_type=hs.TERM_ITER, kernel=hs.KERNEL_STRIP, **kw)
     for bad, status in ((dict(width=0, height=5), hs._lib.E_SIZE), (dict(width=5, height=5, n_pairs=0), hs._lib.E_SIZE)):
         with pytest.raises(hs.HsflowError) as e:
             hs.plan_query(bad.get("width"), bad.get("height"), bad.get("n_pairs", 1), max_iter=5)
