@@ -433,6 +433,28 @@ def main():
             del src, dst
         except RuntimeError:
             pass
+    # the reference's own OpenCL discretisation (Kernels.cl, `-cl` route: 8-neighbour mean, alpha^2, IEEE division) on the
+    # same frames, beside the headline: a side figure, never `value`
+    if rank == 0 and not args.no_side and args.kernel == "auto":
+        try:
+            pc = ctx.make_params(mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=iters, term_type=hs.TERM_ITER)
+            for _ in range(5):
+                ctx.solve_async(pc)
+            ctx.synchronize()
+            nc = max(5, min(args.steps, 50))
+            t0 = time.perf_counter()
+            for _ in range(nc):
+                ctx.solve_async(pc)
+            ctx.synchronize()
+            cms = (time.perf_counter() - t0) / nc * 1e3
+            ic = ctx.info()
+            out["classic_mode"] = {"what": "Kernels.cl discretisation (v update restored), alpha 15, ITER, %d sweeps, same frames" % iters,
+                                   "ms_per_step": cms, "value": px * iters / (cms * 1e-3) / 1e6, "unit": "Mpix*iter/s",
+                                   "kernel": {hs.KERNEL_STRIP: "strip", hs.KERNEL_FUSED: "fused", hs.KERNEL_SIMPLE: "simple"}.get(ic["kernel"], str(ic["kernel"])),
+                                   "fuse_steps": ic["fuse_steps"], "rows_per_lane_or_groups": ic["groups_per_thread"], "threads": ic["threads"],
+                                   "launches": ic["jacobi_launches"]}
+        except hs.HsflowError as e:
+            out["classic_mode"] = {"error": str(e)}
     ctx.close()
 
     # --- multi-GPU configs of BASELINE.json beside the headline ---------------------------------------------

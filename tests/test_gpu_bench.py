@@ -35,6 +35,8 @@ def test_bench_single_gpu_line(gpu_ok):
     # the headline is the reference's own call form (ITER|EPS, eps 1e-6), ITER beside it; no early stop on this pair
     assert d["config"]["termination"].startswith("ITER|EPS") and d["config"]["iterations_done"] == 100 and d["config"]["eps_rerun"] == 0
     assert d["other_termination"]["termination"] == "ITER" and d["other_termination"]["ms_per_step"] > 0
+    # the reference's OpenCL discretisation on the same frames, as a side figure (register-strip kernel at this size)
+    assert d["classic_mode"]["kernel"] == "strip" and 0 < d["classic_mode"]["ms_per_step"] < 5
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and len(d["ms_per_step_blocks"]) == 5
     assert d["ms_per_step_blocks"][0] == d["ms_per_step"]
     rf = d["roofline"]
