@@ -20,7 +20,13 @@ run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5
   echo "# slab driver, one rank, 16384 x 2048, 100 it, halo 16 (tools/bench_slab.py)"
   run python tools/bench_slab.py --width 16384 --height 2048 --iters 100 --halo 16 --steps 3 2>> "$OUT/err.txt" || exit 8
 } > "$OUT/bench_misc.txt"
-run python tools/bench_classic.py > "$OUT/bench_classic.txt" 2>> "$OUT/err.txt" || exit 9
+{
+  echo "# classic mode (Kernels.cl discretisation): the planner's choice (register strip), then the LDS-tile kernel, 1080p/100; then 4K/200"
+  run python tools/bench_classic.py --steps 100 2>> "$OUT/err.txt" || exit 9
+  run python tools/bench_classic.py --steps 100 --kernel fused 2>> "$OUT/err.txt" || exit 9
+  run python tools/bench_classic.py --width 3840 --height 2160 --iters 200 --steps 20 2>> "$OUT/err.txt" || exit 9
+  run python tools/bench_classic.py --width 3840 --height 2160 --iters 200 --steps 20 --kernel fused 2>> "$OUT/err.txt" || exit 9
+} > "$OUT/bench_classic.txt"
 run python tools/bench_e2e.py > "$OUT/e2e_pipeline.txt" 2>> "$OUT/err.txt" || exit 10
 { run python tools/crossover.py 100; run python tools/crossover.py 10; } > "$OUT/crossover.txt" 2>> "$OUT/err.txt" || exit 11
 run python tools/time_cases.py > "$OUT/time_cases.txt" 2>> "$OUT/err.txt" || exit 12
