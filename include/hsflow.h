@@ -59,7 +59,11 @@ extern "C" {
 #define HSFLOW_MODE_CV 0      /* cvCalcOpticalFlowHS semantics: Sobel/8 on frame A, 4-neighbour
                                  mean, lambda (graded parity target)            */
 #define HSFLOW_MODE_CLASSIC 1 /* Kernels.cl semantics: 2x2x2 cube derivatives, 1/6-1/12 mean,
-                                 alpha^2, with the v update restored    */
+                                 alpha^2, with the v update restored.
+                                 ITER termination only (the reference's loop has no other rule).
+                                 Kernels: SIMPLE, FUSED, STRIP (rows per lane 2..8); AUTO takes
+                                 STRIP wherever the image has an aligned shape for it and
+                                 2^-20 <= alpha <= 2^20, else FUSED.  All bit-identical.          */
 
 #define HSFLOW_MODE_CLASSIC_AS_SHIPPED 2 /* Kernels.cl exactly as shipped: u_v_updateKernel writes u only
                                  (Kernels.cl:86), v stays at its starting value.  Reproduces the
