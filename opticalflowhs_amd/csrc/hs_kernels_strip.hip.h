@@ -18,17 +18,11 @@
 #ifndef HS_UNROLL2_FOLD
 #define HS_UNROLL2_FOLD 1
 #endif
-#ifndef HS_UNROLL2
-#define HS_UNROLL2 0
-#endif
 #ifndef HS_PEEL_LAST_STRIP
 #define HS_PEEL_LAST_STRIP 1
 #endif
 #ifndef HS_PEEL_LAST_FOLD
 #define HS_PEEL_LAST_FOLD 1
-#endif
-#ifndef HS_UNGATED_CORE
-#define HS_UNGATED_CORE 0 /* experiment, rejected: two copies of the sweep body make the register allocator spill 66 registers */
 #endif
 #ifndef HS_SWEEP_STAMPS
 #define HS_SWEEP_STAMPS 0
@@ -283,17 +277,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = g.NW;
     float *eps_lds = (float *)(ex + (size_t)2 * NW * 4 * 64);
-    // Synchronisation between sweeps: ONE workgroup barrier per sweep.  Experiment kept behind
-    // HS_STRIP_P2P (default 0, measured SLOWER: 0.220 vs 0.200 ms at 1080p / 100 sweeps): a wavefront only
-    // depends on the strips directly above and below, so each wavefront raises a counter in LDS once its
-    // edge rows of a sweep are published and waits only for its two neighbours' counters.  LDS executes a
-    // wavefront's requests in order, so "counter >= s" implies that neighbour's rows for sweep s are in
-    // place AND that its reads of the buffer about to be overwritten are done (they precede its publish).
-#ifndef HS_STRIP_P2P
-#define HS_STRIP_P2P 0
-#endif
-    constexpr bool P2P = HS_STRIP_P2P && EPS != 1; // the per-sweep Eps fold of EPS == 1 relies on the barrier
-    volatile unsigned *flags = (volatile unsigned *)(eps_lds + 32); // [NW] sweeps published so far
+    // Synchronisation between sweeps: ONE workgroup barrier per sweep.  (Tried and measured slower, 0.220 vs 0.200 ms
+    // at 1080p / 100 sweeps in round 1: per-wavefront counters in LDS, each wavefront waiting only for the strips
+    // directly above and below.)
     const int tpp = g.tiles_x * g.tiles_y;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const int pair = tile / tpp;
@@ -400,9 +386,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (j >= g.T && j < g.T + g.CH && y >= 0 && y < g.H) rowcore |= 1u << r;
         rdist[r] = j < g.T ? g.T - j : (j >= g.T + g.CH ? j - (g.T + g.CH - 1) : 0);
     }
-    bool allcore = true; // every row of this wavefront is swept in every sweep (wave-uniform)
-#pragma unroll
-    for (int r = 0; r < R; r++) allcore = allcore && rdist[r] == 0;
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
     if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
@@ -414,7 +397,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // One row: neighbour sums from the cross sums of its two boundaries (sc below, sp above), update in place.
     // A row at distance d from the core is only needed through sweep T-1-d (trapezoid): later sweeps skip it
     // (wave-uniform branch), which trims the redundant halo work by about half.  PE = parity of the row's pixel p0.
-#define HS_ACT(r) (!GATED || rdist[r] <= last)
+#define HS_ACT(r) (rdist[r] <= last)
 #define HS_ROW(r, PE, SC, SP)                                                                      \
     do {                                                                                           \
         if (HS_ACT(r)) {                                                                           \
@@ -439,8 +422,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
-        /* straight-line form: keep the rows apart, or the scheduler overlaps them all and spills */ \
-        if (!GATED) __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
     // cross sums of the boundary below register row A (row B underneath), needed while either row is still swept
 #define HS_CROSS(S, PE, A, B)                                                                      \
@@ -449,7 +430,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             if (HS_DIAG & 8) S.uP = uP[A] + uP[B];                                                 \
             else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
         }                                                                                          \
-        if (!GATED) __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
 #define HS_PUBLISH(buf)                                                                            \
     do {                                                                                           \
@@ -493,11 +473,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
     // row 0 (image row y0 + image column x0, x0 % 4 == 0): wave-uniform, rows alternate from there.
-    // GATED = false: the straight-line form for wavefronts whose rows are all core rows (never skipped): no compare and
-    // branch per row and per boundary -- these wavefronts are the ones every sweep waits for.
-    auto sweep_g = [&](const int s, auto em_tag, auto gated_tag) __attribute__((always_inline)) {
+    // (A second, straight-line copy of the sweep for wavefronts whose rows are all core rows -- no compare and branch per
+    // row -- was tried and rejected: two copies of the body make the register allocator spill 66 registers.)
+    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
-        constexpr bool GATED = decltype(gated_tag)::value;
 #if HS_DIAG & 4 /* diagnostic build: every row swept in every sweep (no trapezoid) */
         const int last = 1 << 20;
 #else
@@ -528,7 +507,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (wturn) w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
         // --- first row (the strip's upper edge)
         if (HS_ACT(0)) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
-        if (!GATED) __builtin_amdgcn_sched_barrier(0);
         if (R == 1) {
             if (HS_ACT(0)) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
         } else {
@@ -546,8 +524,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
             if (HS_ACT(R - 1)) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
-            if (!GATED) __builtin_amdgcn_sched_barrier(0);
-            if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
+                if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
             if (R == 2) HS_ROW(R - 1, EL, sL, s0);
             else HS_ROW(R - 1, EL, sL, sK);
         }
@@ -594,13 +571,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 32 + (s & 31)] = __builtin_amdgcn_s_memtime();
 #endif
     };
-    auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
-#if HS_UNGATED_CORE
-        if (allcore) sweep_g(s, em_tag, std::false_type{});
-        else
-#endif
-            sweep_g(s, em_tag, std::true_type{});
-    };
     if constexpr (EPS == 3) {
 #pragma unroll 1
         for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, 2>{});
@@ -609,14 +579,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #pragma unroll 1
         for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
         sweep(g.T - 1, std::integral_constant<int, EPS>{});
-    } else if constexpr (HS_UNROLL2 && EPS != 1) { // EXPERIMENT: two sweeps per loop trip
-        int s = 0;
-#pragma unroll 1
-        for (; s + 1 < g.T; s += 2) {
-            sweep(s, std::integral_constant<int, EPS>{});
-            sweep(s + 1, std::integral_constant<int, EPS>{});
-        }
-        if (s < g.T) sweep(s, std::integral_constant<int, EPS>{});
     } else {
 #pragma unroll 1
         for (int s = 0; s < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
@@ -655,20 +617,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         for (int r = 0; r < R; r++) {
             if ((rowcore >> r) & 1u) {
                 const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
-#if defined(HS_EXP_NT_STORE) /* experiment (slower): non-temporal stores */
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, (v4f *)(u_out + off));
-                __builtin_nontemporal_store(v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y}, (v4f *)(v_out + off));
-#elif defined(HS_EXP_SC1_STORE) /* experiment: agent-scope write-through stores (nothing dirty at kernel end) */
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f su_ = v4f{uP[r].x, uP[r].y, uQ[r].x, uQ[r].y}, sv_ = v4f{vP[r].x, vP[r].y, vQ[r].x, vQ[r].y};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(u_out + off), "v"(su_) : "memory");
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(v_out + off), "v"(sv_) : "memory");
-#else
+                // (non-temporal and agent-scope write-through stores were tried here: both slower)
                 const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
                 *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
                 *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
-#endif
             }
         }
     }
