@@ -460,10 +460,17 @@ def main():
     # --- multi-GPU configs of BASELINE.json beside the headline ---------------------------------------------
     want_c4 = args.c4 == "on" or (args.c4 == "auto" and world > 1)
     want_c5 = args.c5 == "on" or (args.c5 == "auto" and world > 1)
+    # (a failure in one of these must not cost the headline: it is recorded under the key instead)
     if want_c4:
-        out["c4_pipeline"] = run_c4(args, hs, synth, dist, world, rank, local_rank, barrier, reduce_max)
+        try:
+            out["c4_pipeline"] = run_c4(args, hs, synth, dist, world, rank, local_rank, barrier, reduce_max)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, the run goes on
+            out["c4_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if want_c5:
-        out["c5_slab"] = run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max)
+        try:
+            out["c5_slab"] = run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max)
+        except Exception as e:  # noqa: BLE001
+            out["c5_slab"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.skip_cpu:
         from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
