@@ -474,7 +474,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
     // row 0 (image row y0 + image column x0, x0 % 4 == 0): wave-uniform, rows alternate from there.
     // (A second, straight-line copy of the sweep for wavefronts whose rows are all core rows -- no compare and branch per
-    // row -- was tried and rejected: two copies of the body make the register allocator spill 66 registers.)
+    // row -- was tried and rejected: two copies of the body make the register allocator spill 66 registers.  So was a
+    // trapezoid per WAVEFRONT instead of per row, one branch per sweep: 16 -> 3 branches and 40 -> 12 scalar instructions
+    // in the loop, but the straight-line body keeps more values alive and the ITER kernel then spills inside the loop:
+    // ITER|EPS 0.1573 -> 0.1556 ms, ITER 0.1522 -> 0.1555 ms at 1080p / 100.)
     auto sweep = [&](const int s, auto em_tag) __attribute__((always_inline)) {
         constexpr int EM = decltype(em_tag)::value;
 #if HS_DIAG & 4 /* diagnostic build: every row swept in every sweep (no trapezoid) */
