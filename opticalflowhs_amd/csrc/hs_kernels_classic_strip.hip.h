@@ -64,6 +64,21 @@ __device__ __forceinline__ float div_by(float n, float d, float r)
     return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1, r, q1, scaled), d, n);
 }
 
+// Two quotients at once: the four multiply / fused multiply-add steps of div_by as packed instructions (v_pk_mul_f32,
+// v_pk_fma_f32 round each half exactly like their scalar forms).
+typedef float f2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2c div_by2(f2c n, f2c d, f2c r)
+{
+    bool sx, sy;
+    const f2c ns = f2c{__builtin_amdgcn_div_scalef(n.x, d.x, true, &sx), __builtin_amdgcn_div_scalef(n.y, d.y, true, &sy)};
+    const f2c q0 = ns * r;
+    const f2c e0 = __builtin_elementwise_fma(-d, q0, ns);
+    const f2c q1 = __builtin_elementwise_fma(e0, r, q0);
+    const f2c e1 = __builtin_elementwise_fma(-d, q1, ns);
+    return f2c{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.x, r.x, q1.x, sx), d.x, n.x),
+               __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.y, r.y, q1.y, sy), d.y, n.y)};
+}
+
 struct CWin { float l, c0, c1, c2, c3, r; }; // columns x0-1 .. x0+4 of one row of one plane
 struct CH4 { float h0, h1, h2, h3; };         // L + R of the four pixels
 
@@ -217,22 +232,33 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                     pnu[0] = hnu.h0 + u[r][0]; pnu[1] = hnu.h1 + u[r][1]; pnu[2] = hnu.h2 + u[r][2]; pnu[3] = hnu.h3 + u[r][3];
                     pnv[0] = hnv.h0 + v[r][0]; pnv[1] = hnv.h1 + v[r][1]; pnv[2] = hnv.h2 + v[r][2]; pnv[3] = hnv.h3 + v[r][3];
                 }
-                // Kernels.cl:55-63: c6 * (((L + R) + U) + D) + c12 * (((UL + UR) + DL) + DR)
-                const float ua[4] = {c6 * (peu[0] + Nu.c0) + c12 * ((hpu.h0 + Nu.l) + Nu.c1),
-                                     c6 * (peu[1] + Nu.c1) + c12 * ((hpu.h1 + Nu.c0) + Nu.c2),
-                                     c6 * (peu[2] + Nu.c2) + c12 * ((hpu.h2 + Nu.c1) + Nu.c3),
-                                     c6 * (peu[3] + Nu.c3) + c12 * ((hpu.h3 + Nu.c2) + Nu.r)};
-                const float va[4] = {c6 * (pev[0] + Nv.c0) + c12 * ((hpv.h0 + Nv.l) + Nv.c1),
-                                     c6 * (pev[1] + Nv.c1) + c12 * ((hpv.h1 + Nv.c0) + Nv.c2),
-                                     c6 * (pev[2] + Nv.c2) + c12 * ((hpv.h2 + Nv.c1) + Nv.c3),
-                                     c6 * (pev[3] + Nv.c3) + c12 * ((hpv.h3 + Nv.c2) + Nv.r)};
+                // Kernels.cl:55-63: c6 * (((L + R) + U) + D) + c12 * (((UL + UR) + DL) + DR); pairs of pixels as packed
+                // operations where both operands are register pairs (the edge term, the weights, the update)
+                const f2c k6 = f2c{c6, c6}, k12 = f2c{c12, c12};
+                const f2c euA = f2c{peu[0], peu[1]} + f2c{Nu.c0, Nu.c1}, euB = f2c{peu[2], peu[3]} + f2c{Nu.c2, Nu.c3};
+                const f2c evA = f2c{pev[0], pev[1]} + f2c{Nv.c0, Nv.c1}, evB = f2c{pev[2], pev[3]} + f2c{Nv.c2, Nv.c3};
+                const f2c cuA = f2c{(hpu.h0 + Nu.l) + Nu.c1, (hpu.h1 + Nu.c0) + Nu.c2}, cuB = f2c{(hpu.h2 + Nu.c1) + Nu.c3, (hpu.h3 + Nu.c2) + Nu.r};
+                const f2c cvA = f2c{(hpv.h0 + Nv.l) + Nv.c1, (hpv.h1 + Nv.c0) + Nv.c2}, cvB = f2c{(hpv.h2 + Nv.c1) + Nv.c3, (hpv.h3 + Nv.c2) + Nv.r};
+                const f2c uaA = k6 * euA + k12 * cuA, uaB = k6 * euB + k12 * cuB;
+                const f2c vaA = k6 * evA + k12 * cvA, vaB = k6 * evB + k12 * cvB;
 #pragma unroll
-                for (int p = 0; p < 4; p++) { // Kernels.cl:84-86
-                    float t = cEx[r][p] * ua[p] + cEy[r][p] * va[p] + cEt[r][p];
-                    if constexpr (RCP) t = div_by(t, cDn[r][p], cRc[r][p]); // (no division at all would save 0.04 ms of 0.46)
-                    else t /= cDn[r][p];
-                    u[r][p] = ua[p] - cEx[r][p] * t;
-                    if (WRITE_V) v[r][p] = va[p] - cEy[r][p] * t; // restored: the reference kernel forgot this line
+                for (int h = 0; h < 2; h++) { // Kernels.cl:84-86, two pixels at a time
+                    const f2c ua2 = h ? uaB : uaA, va2 = h ? vaB : vaA;
+                    const f2c ex2 = f2c{cEx[r][2 * h], cEx[r][2 * h + 1]}, ey2 = f2c{cEy[r][2 * h], cEy[r][2 * h + 1]},
+                              et2 = f2c{cEt[r][2 * h], cEt[r][2 * h + 1]};
+                    f2c t2 = ex2 * ua2 + ey2 * va2 + et2;
+                    if constexpr (RCP) {
+                        t2 = div_by2(t2, f2c{cDn[r][2 * h], cDn[r][2 * h + 1]}, f2c{cRc[r][2 * h], cRc[r][2 * h + 1]});
+                    } else {
+                        t2.x /= cDn[r][2 * h];
+                        t2.y /= cDn[r][2 * h + 1];
+                    }
+                    const f2c un = ua2 - ex2 * t2;
+                    u[r][2 * h] = un.x; u[r][2 * h + 1] = un.y;
+                    if (WRITE_V) { // restored: the reference kernel forgot this line
+                        const f2c vn = va2 - ey2 * t2;
+                        v[r][2 * h] = vn.x; v[r][2 * h + 1] = vn.y;
+                    }
                 }
                 if (GHOST) { // pixels right of column W-1 inside a lane replicate column W-1
                     u[r][1] = pr == 0 ? u[r][0] : u[r][1]; v[r][1] = pr == 0 ? v[r][0] : v[r][1];
