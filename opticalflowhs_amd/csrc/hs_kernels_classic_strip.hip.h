@@ -233,7 +233,10 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                     pnv[0] = hnv.h0 + v[r][0]; pnv[1] = hnv.h1 + v[r][1]; pnv[2] = hnv.h2 + v[r][2]; pnv[3] = hnv.h3 + v[r][3];
                 }
                 // Kernels.cl:55-63: c6 * (((L + R) + U) + D) + c12 * (((UL + UR) + DL) + DR); pairs of pixels as packed
-                // operations where both operands are register pairs (the edge term, the weights, the update)
+                // operations where both operands are register pairs (the edge term, the weights, the update): -15 % per
+                // solve.  (Holding a lane's pixels as the pairs (p0, p3), (p1, p2) makes the L+R sums and the carried sums
+                // packed as well -- 8 instructions fewer per row -- but measured no faster at 512 threads and slower at
+                // 1024, where it spills: not kept.)
                 const f2c k6 = f2c{c6, c6}, k12 = f2c{c12, c12};
                 const f2c euA = f2c{peu[0], peu[1]} + f2c{Nu.c0, Nu.c1}, euB = f2c{peu[2], peu[3]} + f2c{Nu.c2, Nu.c3};
                 const f2c evA = f2c{pev[0], pev[1]} + f2c{Nv.c0, Nv.c1}, evB = f2c{pev[2], pev[3]} + f2c{Nv.c2, Nv.c3};

@@ -164,7 +164,7 @@ bool classic_strip_geom(const hsflow_ctx *c, int T, int R, int NW, hsk::ClassicS
 
 // Modelled time of one launch in microseconds, fitted to tools/sweep_classic_strip.py on MI355X at 480p, 720p, 1080p and
 // 4K (profiles/r02_sweep_classic_strip.txt; within 10 % there): a launch gap, the planes through the cache hierarchy
-// (20 bytes per pixel at ~12 TB/s), then per round of workgroups the rows the busiest SIMD holds, each loaded and
+// (12 bytes per pixel in, 8 out), then per round of workgroups the rows the busiest SIMD holds, each loaded and
 // unpacked once and swept T times (halo wavefronts drop out one by one, fewer resident wavefronts hide less latency).
 double classic_strip_launch_us(const hsflow_ctx *c, const hsk::ClassicStripGeom &g, int R, long long tiles, int *wg_per_cu_out = nullptr)
 {
@@ -175,10 +175,12 @@ double classic_strip_launch_us(const hsflow_ctx *c, const hsk::ClassicStripGeom 
     const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // workgroups sharing a CU
     const double wps = (double)((NW + 3) / 4) * (double)conc;                              // wavefronts on the busiest SIMD
     const double rps = wps * R;                                                              // ... and their rows
-    const double few = wps >= 3.5 ? 1.0 : (wps >= 2.5 ? 1.1 : (wps >= 1.5 ? 1.2 : 1.5));
+    // per row and sweep: 0.176 us for the shapes that divide with the precomputed reciprocal (R = 2, 3, 6), 0.215 for the
+    // others; a single wavefront per SIMD hides less latency (two are as good as four since the arithmetic is packed)
+    const double row_us = ((R <= 3 || R == 6) ? 0.176 : 0.215) * (wps >= 1.5 ? 1.0 : 1.3);
     const double halo_frac = std::min(1.0, 2.0 * g.TH / (double)(NW * R));
-    const double bytes_us = (double)g.W * g.H * c->N * 20.0 / 12e6;
-    return 2.0 + bytes_us + rounds * rps * (0.32 + 0.22 * few * g.T * (1.0 - 0.25 * halo_frac));
+    const double bytes_us = (double)g.W * g.H * c->N * 12.0 / 7e6;
+    return 2.0 + bytes_us + rounds * rps * (0.32 + row_us * g.T * (1.0 - 0.25 * halo_frac));
 }
 
 bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, ClassicStripPlan &best, double *cost_out = nullptr)
@@ -192,7 +194,8 @@ bool make_classic_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, 
             hsk::ClassicStripGeom g;
             if (!classic_strip_geom(c, T, R, NW, g)) continue;
             const long long tiles = (long long)g.tiles_x * g.tiles_y * c->N;
-            const double cost = classic_strip_launch_us(c, g, R, tiles);
+            // (equal in the model: the same rows per SIMD in fewer, longer wavefronts measure 1 - 3 % faster)
+            const double cost = classic_strip_launch_us(c, g, R, tiles) * (1.0 - 0.004 * R);
             if (cost < best_cost) {
                 best_cost = cost;
                 found = true;
