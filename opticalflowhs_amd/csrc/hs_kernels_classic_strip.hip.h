@@ -212,8 +212,8 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
             const CWin Cu = window(u[0][0], u[0][1], u[0][2], u[0][3]), Cv = window(v[0][0], v[0][1], v[0][2], v[0][3]);
             CH4 hcu = hsum(Cu), hcv = hsum(Cv); // ... of the old row r
             // (L+R of row r) + (centre of old row r-1)
-            float peu[4] = {hcu.h0 + Uu.c0, hcu.h1 + Uu.c1, hcu.h2 + Uu.c2, hcu.h3 + Uu.c3};
-            float pev[4] = {hcv.h0 + Uv.c0, hcv.h1 + Uv.c1, hcv.h2 + Uv.c2, hcv.h3 + Uv.c3};
+            f2c peuA = f2c{hcu.h0, hcu.h1} + f2c{Uu.c0, Uu.c1}, peuB = f2c{hcu.h2, hcu.h3} + f2c{Uu.c2, Uu.c3};
+            f2c pevA = f2c{hcv.h0, hcv.h1} + f2c{Uv.c0, Uv.c1}, pevB = f2c{hcv.h2, hcv.h3} + f2c{Uv.c2, Uv.c3};
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 float nu0, nu1, nu2, nu3, nv0, nv1, nv2, nv3; // centres of the old row below
@@ -226,11 +226,11 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                 }
                 const CWin Nu = window(nu0, nu1, nu2, nu3), Nv = window(nv0, nv1, nv2, nv3);
                 CH4 hnu, hnv;
-                float pnu[4], pnv[4];
+                f2c pnuA, pnuB, pnvA, pnvB;
                 if (r + 1 < R) { // for the row below, before this row is overwritten
                     hnu = hsum(Nu); hnv = hsum(Nv);
-                    pnu[0] = hnu.h0 + u[r][0]; pnu[1] = hnu.h1 + u[r][1]; pnu[2] = hnu.h2 + u[r][2]; pnu[3] = hnu.h3 + u[r][3];
-                    pnv[0] = hnv.h0 + v[r][0]; pnv[1] = hnv.h1 + v[r][1]; pnv[2] = hnv.h2 + v[r][2]; pnv[3] = hnv.h3 + v[r][3];
+                    pnuA = f2c{hnu.h0, hnu.h1} + f2c{u[r][0], u[r][1]}; pnuB = f2c{hnu.h2, hnu.h3} + f2c{u[r][2], u[r][3]};
+                    pnvA = f2c{hnv.h0, hnv.h1} + f2c{v[r][0], v[r][1]}; pnvB = f2c{hnv.h2, hnv.h3} + f2c{v[r][2], v[r][3]};
                 }
                 // Kernels.cl:55-63: c6 * (((L + R) + U) + D) + c12 * (((UL + UR) + DL) + DR); pairs of pixels as packed
                 // operations where both operands are register pairs (the edge term, the weights, the update): -15 % per
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                 // packed as well -- 8 instructions fewer per row -- but measured no faster at 512 threads and slower at
                 // 1024, where it spills: not kept.)
                 const f2c k6 = f2c{c6, c6}, k12 = f2c{c12, c12};
-                const f2c euA = f2c{peu[0], peu[1]} + f2c{Nu.c0, Nu.c1}, euB = f2c{peu[2], peu[3]} + f2c{Nu.c2, Nu.c3};
-                const f2c evA = f2c{pev[0], pev[1]} + f2c{Nv.c0, Nv.c1}, evB = f2c{pev[2], pev[3]} + f2c{Nv.c2, Nv.c3};
+                const f2c euA = peuA + f2c{Nu.c0, Nu.c1}, euB = peuB + f2c{Nu.c2, Nu.c3};
+                const f2c evA = pevA + f2c{Nv.c0, Nv.c1}, evB = pevB + f2c{Nv.c2, Nv.c3};
                 const f2c cuA = f2c{(hpu.h0 + Nu.l) + Nu.c1, (hpu.h1 + Nu.c0) + Nu.c2}, cuB = f2c{(hpu.h2 + Nu.c1) + Nu.c3, (hpu.h3 + Nu.c2) + Nu.r};
                 const f2c cvA = f2c{(hpv.h0 + Nv.l) + Nv.c1, (hpv.h1 + Nv.c0) + Nv.c2}, cvB = f2c{(hpv.h2 + Nv.c1) + Nv.c3, (hpv.h3 + Nv.c2) + Nv.r};
                 const f2c uaA = k6 * euA + k12 * cuA, uaB = k6 * euB + k12 * cuB;
@@ -271,8 +271,7 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                 if (r + 1 < R) {
                     hpu = hcu; hpv = hcv;
                     hcu = hnu; hcv = hnv;
-#pragma unroll
-                    for (int p = 0; p < 4; p++) { peu[p] = pnu[p]; pev[p] = pnv[p]; }
+                    peuA = pnuA; peuB = pnuB; pevA = pnvA; pevB = pnvB;
                 }
             }
         }
