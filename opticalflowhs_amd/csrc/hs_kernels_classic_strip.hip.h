@@ -46,7 +46,7 @@ struct ClassicStripGeom {
 // numerator keeps its v_div_scale (tiny numerators -- flow that has only just reached a static area -- are scaled by
 // 2^64 for the residuals and scaled back by v_div_fmas, as in the compiler's sequence).  Same instructions on the same
 // operands: the same bits (tests: bit-exact against oracle/hs_classic_oracle.c, which divides with `/`).
-// It costs one more register per pixel: used by the shapes that have them (R = 2, 3 at 1024 threads, R = 6 at 512).
+// It costs one more register per pixel: used by the shapes that have them (R = 2, 3 at 1024 threads, 4 at 768, 6 at 512).
 __device__ __forceinline__ float refined_rcp(float d)
 {
     const float r0 = __builtin_amdgcn_rcpf(d);
@@ -75,6 +75,25 @@ __device__ __forceinline__ f2c div_by2(f2c n, f2c d, f2c r)
     const f2c e0 = __builtin_elementwise_fma(-d, q0, ns);
     const f2c q1 = __builtin_elementwise_fma(e0, r, q0);
     const f2c e1 = __builtin_elementwise_fma(-d, q1, ns);
+    return f2c{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.x, r.x, q1.x, sx), d.x, n.x),
+               __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.y, r.y, q1.y, sy), d.y, n.y)};
+}
+
+// The shapes without a register for the reciprocal divide with the complete sequence, two quotients at a time: the
+// compiler's own expansion of `/` (v_div_scale of both operands, v_rcp, two refinement steps, quotient, two residual
+// steps, v_div_fmas, v_div_fixup) with its six multiply / fused multiply-add steps packed.
+__device__ __forceinline__ f2c div_full2(f2c n, f2c d)
+{
+    bool sx, sy, tx, ty;
+    const f2c ds = f2c{__builtin_amdgcn_div_scalef(n.x, d.x, false, &tx), __builtin_amdgcn_div_scalef(n.y, d.y, false, &ty)};
+    const f2c ns = f2c{__builtin_amdgcn_div_scalef(n.x, d.x, true, &sx), __builtin_amdgcn_div_scalef(n.y, d.y, true, &sy)};
+    const f2c r0 = f2c{__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
+    const f2c e = __builtin_elementwise_fma(-ds, r0, f2c{1.0f, 1.0f});
+    const f2c r = __builtin_elementwise_fma(e, r0, r0);
+    const f2c q0 = ns * r;
+    const f2c e0 = __builtin_elementwise_fma(-ds, q0, ns);
+    const f2c q1 = __builtin_elementwise_fma(e0, r, q0);
+    const f2c e1 = __builtin_elementwise_fma(-ds, q1, ns);
     return f2c{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.x, r.x, q1.x, sx), d.x, n.x),
                __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e1.y, r.y, q1.y, sy), d.y, n.y)};
 }
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
         }
     }
     float u[R][4], v[R][4], cEx[R][4], cEy[R][4], cEt[R][4], cDn[R][4];
-    constexpr bool RCP = R <= 3 || R == 6; // the division with the reciprocal precomputed (div_by)
+    constexpr bool RCP = R <= 4 || R == 6; // the division with the reciprocal precomputed (div_by2)
     float cRc[RCP ? R : 1][4];
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -253,8 +272,7 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                     if constexpr (RCP) {
                         t2 = div_by2(t2, f2c{cDn[r][2 * h], cDn[r][2 * h + 1]}, f2c{cRc[r][2 * h], cRc[r][2 * h + 1]});
                     } else {
-                        t2.x /= cDn[r][2 * h];
-                        t2.y /= cDn[r][2 * h + 1];
+                        t2 = div_full2(t2, f2c{cDn[r][2 * h], cDn[r][2 * h + 1]});
                     }
                     const f2c un = ua2 - ex2 * t2;
                     u[r][2 * h] = un.x; u[r][2 * h + 1] = un.y;

@@ -175,9 +175,9 @@ double classic_strip_launch_us(const hsflow_ctx *c, const hsk::ClassicStripGeom 
     const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // workgroups sharing a CU
     const double wps = (double)((NW + 3) / 4) * (double)conc;                              // wavefronts on the busiest SIMD
     const double rps = wps * R;                                                              // ... and their rows
-    // per row and sweep: 0.176 us for the shapes that divide with the precomputed reciprocal (R = 2, 3, 6), 0.215 for the
+    // per row and sweep: 0.176 us for the shapes that divide with the precomputed reciprocal (R = 2, 3, 4, 6), 0.2 for the
     // others; a single wavefront per SIMD hides less latency (two are as good as four since the arithmetic is packed)
-    const double row_us = ((R <= 3 || R == 6) ? 0.176 : 0.215) * (wps >= 1.5 ? 1.0 : 1.3);
+    const double row_us = ((R <= 4 || R == 6) ? 0.176 : 0.2) * (wps >= 1.5 ? 1.0 : 1.3);
     const double halo_frac = std::min(1.0, 2.0 * g.TH / (double)(NW * R));
     const double bytes_us = (double)g.W * g.H * c->N * 12.0 / 7e6;
     return 2.0 + bytes_us + rounds * rps * (0.32 + row_us * g.T * (1.0 - 0.25 * halo_frac));

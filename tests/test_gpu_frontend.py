@@ -321,7 +321,8 @@ def test_classic_strip_kernel_bit_exact(hs, oracle, gpu_ok):
         assert tiny.min() < 1e-36 and (uo == 0).any() and tiny.max() > 1e-3, (tiny.min(), tiny.max())
         with hs.HSFlow(W, H, own_stream=True) as ctx:
             ctx.set_frames(A, B)
-            for kw in (dict(), dict(strip_rows=6), dict(strip_rows=4), dict(strip_rows=2, fuse_steps=3)):
+            for kw in (dict(), dict(strip_rows=6), dict(strip_rows=4), dict(strip_rows=2, fuse_steps=3),
+                       dict(strip_rows=5), dict(strip_rows=8, fuse_steps=5), dict(strip_rows=7)):  # (5, 7, 8: the complete division, packed)
                 info = ctx.solve(mode=hs.MODE_CLASSIC, alpha=alpha, max_iter=it, term_type=ITER, kernel=hs.KERNEL_STRIP, **kw)
                 u, v = ctx.flow()
                 assert np.array_equal(u, uo) and np.array_equal(v, vo), (alpha, kw, info, np.argwhere(u != uo)[:4])
