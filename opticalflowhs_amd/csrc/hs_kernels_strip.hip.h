@@ -27,6 +27,9 @@
 #ifndef HS_SWEEP_STAMPS
 #define HS_SWEEP_STAMPS 0
 #endif
+#ifndef HS_PAIR_MS /* strip kernel: a lane's pixels p0..p3 as the register pairs (p0, p3), (p1, p2) instead of (p0, p1), (p2, p3) */
+#define HS_PAIR_MS 1
+#endif
 #ifndef HS_DIAG /* bit mask of diagnostic knobs in the strip sweep (timing experiments only, results are wrong): 1 no LDS
                    exchange, 2 no barrier, 4 no trapezoid gating, 8 no arithmetic */
 #define HS_DIAG 0
@@ -139,6 +142,64 @@ __device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ,
     } else {
         tP = sc.uP + f2_swap(sp.uP); tQ = sc.uQ + f2_swap(sp.uQ);
         sP = sc.vP + f2_swap(sp.vP); sQ = sc.vQ + f2_swap(sp.vQ);
+    }
+#if HS_SCALED
+    const f2 ubP = tP, ubQ = tQ, vbP = sP, vbQ = sQ; // 4^(k+1) * average
+#else
+    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f, vbP = sP * 0.25f, vbQ = sQ * 0.25f;
+#endif
+    const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
+    const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
+    uP = f2_fma(-c.alP, qP, ubP);
+    vP = f2_fma(-c.beP, qP, vbP);
+    uQ = f2_fma(-c.alQ, qQ, ubQ);
+    vQ = f2_fma(-c.beQ, qQ, vbQ);
+#if HS_SCALED
+    c.gaP *= 4.0f; // the constant term at the next sweep's scale
+    c.gaQ *= 4.0f;
+#endif
+}
+
+// The same two steps for the strip kernel's pairing P = (p0, p3), Q = (p1, p2) (HS_PAIR_MS): where the partner of a pixel
+// is the other pixel of its lane's INNER pair the sum is one packed add with swapped halves, and the outer pixels reach
+// into the adjacent lanes (two DPP adds); where partners lie in the other pair of the lane, two plain packed adds.  A
+// row costs 3 packed + 2 DPP adds per plane (pairing (p0, p1), (p2, p3): 2 packed + 2 DPP + 2 plain).
+// a + swap(b) in one packed add (written out: left to the compiler, the swap of a row that has just come from LDS is
+// done with two moves first)
+__device__ __forceinline__ f2 pk_add_swapped(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int E>
+__device__ __forceinline__ void cross_rows_ms(Cross &s, const f2 cuP, const f2 cuQ, const f2 cvP, const f2 cvQ,
+                                              const f2 duP, const f2 duQ, const f2 dvP, const f2 dvQ)
+{
+    if (E == 0) { // p0 + c1, p3 + c2 | p1 + c0, p2 + c3
+        s.uP = duP + cuQ; s.uQ = duQ + cuP;
+        s.vP = dvP + cvQ; s.vQ = dvQ + cvP;
+    } else {      // p1 + c2, p2 + c1 | p0 + previous lane's c3, p3 + next lane's c0
+        s.uQ = pk_add_swapped(duQ, cuQ);
+        s.uP.x = duP.x + wave_from_prev_lane(cuP.y); s.uP.y = duP.y + wave_from_next_lane(cuP.x);
+        s.vQ = pk_add_swapped(dvQ, cvQ);
+        s.vP.x = dvP.x + wave_from_prev_lane(cvP.y); s.vP.y = dvP.y + wave_from_next_lane(cvP.x);
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void strip_row_update_ms(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const Cross &sc, const Cross &sp, RowCoef &c)
+{
+    f2 tP, tQ, sP, sQ;
+    if (E == 0) {
+        tQ = pk_add_swapped(sc.uQ, sp.uQ);
+        tP.x = sc.uP.x + wave_from_prev_lane(sp.uP.y); tP.y = sc.uP.y + wave_from_next_lane(sp.uP.x);
+        sQ = pk_add_swapped(sc.vQ, sp.vQ);
+        sP.x = sc.vP.x + wave_from_prev_lane(sp.vP.y); sP.y = sc.vP.y + wave_from_next_lane(sp.vP.x);
+    } else {
+        tP = sc.uP + sp.uQ; tQ = sc.uQ + sp.uP;
+        sP = sc.vP + sp.vQ; sQ = sc.vQ + sp.vP;
     }
 #if HS_SCALED
     const f2 ubP = tP, ubQ = tQ, vbP = sP, vbQ = sQ; // 4^(k+1) * average
@@ -367,15 +428,18 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     for (int r = 0; r < R; r++) {
         const float4 lu_ = lu[r], lv_ = lv[r];
         const uint4 cw = lc[r];
-        uP[r] = f2{lu_.x, lu_.y}; uQ[r] = f2{lu_.z, lu_.w};
-        vP[r] = f2{lv_.x, lv_.y}; vQ[r] = f2{lv_.z, lv_.w};
+        // pairing of the lane's pixels p0..p3 into the register pairs P, Q: (p0, p3), (p1, p2) (HS_PAIR_MS; see cross_rows_ms)
+        constexpr int iPx = 0, iPy = HS_PAIR_MS ? 3 : 1, iQx = HS_PAIR_MS ? 1 : 2, iQy = HS_PAIR_MS ? 2 : 3;
+        const float lu4[4] = {lu_.x, lu_.y, lu_.z, lu_.w}, lv4[4] = {lv_.x, lv_.y, lv_.z, lv_.w};
+        uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
+        vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
         float al[4], be[4], ga[4];
         const uint32_t cc[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
         for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
-        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
-        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[2], ga[3]} * (HS_SCALED ? 4.0f : 1.0f);
+        cf[r].alP = f2{al[iPx], al[iPy]}; cf[r].alQ = f2{al[iQx], al[iQy]};
+        cf[r].beP = f2{be[iPx], be[iPy]}; cf[r].beQ = f2{be[iQx], be[iQy]};
+        cf[r].gaP = f2{ga[iPx], ga[iPy]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[iQx], ga[iQy]} * (HS_SCALED ? 4.0f : 1.0f);
     }
     // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
     unsigned rowcore = 0;
@@ -404,6 +468,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             f2 ouP, ouQ, ovP, ovQ;                                                                 \
             if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
             if (HS_DIAG & 8) uP[r] += SC.uP + SP.uP;                                               \
+            else if (HS_PAIR_MS) strip_row_update_ms<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]); \
             else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
             if (EM == 1) {                                                                         \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
@@ -414,10 +479,14 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                         e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                           \
                         e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                           \
                     } else {                                                                       \
+                        /* pixels p0..p3 of the group; image columns are 0..pr */                \
+                        const float d1 = HS_PAIR_MS ? fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)) : fmaxf(fabsf(dUP.y), fabsf(dVP.y)); \
+                        const float d2 = HS_PAIR_MS ? fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)) : fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)); \
+                        const float d3 = HS_PAIR_MS ? fmaxf(fabsf(dUP.y), fabsf(dVP.y)) : fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)); \
                         e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                           \
-                        if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));              \
-                        if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));              \
-                        if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));              \
+                        if (pr >= 1) e = fmaxf(e, d1);                                             \
+                        if (pr >= 2) e = fmaxf(e, d2);                                             \
+                        if (pr >= 3) e = fmaxf(e, d3);                                             \
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
@@ -428,6 +497,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     do {                                                                                           \
         if (HS_ACT(A) || HS_ACT(B)) {                                                              \
             if (HS_DIAG & 8) S.uP = uP[A] + uP[B];                                                 \
+            else if (HS_PAIR_MS) cross_rows_ms<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]); \
             else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
         }                                                                                          \
     } while (0)
@@ -509,9 +579,15 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         float w0 = 0.f;
         if (wturn) w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
         // --- first row (the strip's upper edge)
-        if (HS_ACT(0)) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
+        if (HS_ACT(0)) {
+            if (HS_PAIR_MS) cross_rows_ms<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
+            else cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
+        }
         if (R == 1) {
-            if (HS_ACT(0)) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
+            if (HS_ACT(0)) {
+                if (HS_PAIR_MS) cross_rows_ms<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
+                else cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
+            }
         } else {
             constexpr int R1 = R > 1 ? 1 : 0;
             HS_CROSS(s0, E0, 0, R1);
@@ -526,7 +602,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (R >= 2) {
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
-            if (HS_ACT(R - 1)) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+            if (HS_ACT(R - 1)) {
+                if (HS_PAIR_MS) cross_rows_ms<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+                else cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
+            }
                 if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
             if (R == 2) HS_ROW(R - 1, EL, sL, s0);
             else HS_ROW(R - 1, EL, sL, sK);
@@ -622,8 +701,13 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
                 // (non-temporal and agent-scope write-through stores were tried here: both slower)
                 const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
-                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
+                if (HS_PAIR_MS) { // P = (p0, p3), Q = (p1, p2)
+                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
+                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
+                } else {
+                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
+                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
+                }
             }
         }
     }
