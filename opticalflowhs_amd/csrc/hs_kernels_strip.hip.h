@@ -30,6 +30,9 @@
 #ifndef HS_PAIR_MS /* strip kernel: a lane's pixels p0..p3 as the register pairs (p0, p3), (p1, p2) instead of (p0, p1), (p2, p3) */
 #define HS_PAIR_MS 1
 #endif
+#ifndef HS_PAIR_MS_FOLD /* the same for the folded kernel */
+#define HS_PAIR_MS_FOLD 1
+#endif
 #ifndef HS_DIAG /* bit mask of diagnostic knobs in the strip sweep (timing experiments only, results are wrong): 1 no LDS
                    exchange, 2 no barrier, 4 no trapezoid gating, 8 no arithmetic */
 #define HS_DIAG 0
@@ -869,15 +872,18 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     if (DERIV) strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        uP[r] = f2{lu[r].x, lu[r].y}; uQ[r] = f2{lu[r].z, lu[r].w};
-        vP[r] = f2{lv[r].x, lv[r].y}; vQ[r] = f2{lv[r].z, lv[r].w};
+        // pairing of the lane's pixels p0..p3 into the register pairs P, Q: (p0, p3), (p1, p2) (HS_PAIR_MS_FOLD; see cross_rows_ms)
+        constexpr int iPx = 0, iPy = HS_PAIR_MS_FOLD ? 3 : 1, iQx = HS_PAIR_MS_FOLD ? 1 : 2, iQy = HS_PAIR_MS_FOLD ? 2 : 3;
+        const float lu4[4] = {lu[r].x, lu[r].y, lu[r].z, lu[r].w}, lv4[4] = {lv[r].x, lv[r].y, lv[r].z, lv[r].w};
+        uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
+        vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
         float al[4], be[4], ga[4];
         const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
 #pragma unroll
         for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
-        cf[r].alP = f2{al[0], al[1]}; cf[r].alQ = f2{al[2], al[3]};
-        cf[r].beP = f2{be[0], be[1]}; cf[r].beQ = f2{be[2], be[3]};
-        cf[r].gaP = f2{ga[0], ga[1]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[2], ga[3]} * (HS_SCALED ? 4.0f : 1.0f);
+        cf[r].alP = f2{al[iPx], al[iPy]}; cf[r].alQ = f2{al[iQx], al[iQy]};
+        cf[r].beP = f2{be[iPx], be[iPy]}; cf[r].beQ = f2{be[iQx], be[iQy]};
+        cf[r].gaP = f2{ga[iPx], ga[iPy]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[iQx], ga[iQy]} * (HS_SCALED ? 4.0f : 1.0f);
     }
     // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
     unsigned rowcore = 0;
@@ -905,13 +911,18 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         if (rdist[r] <= last) {                                                                    \
             f2 ouP, ouQ, ovP, ovQ;                                                                 \
             if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
-            strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                       \
+            if (HS_PAIR_MS_FOLD) strip_row_update_ms<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]); \
+            else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
             if (EM == 1) {                                                                         \
                 if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
+                    /* pixels p0..p3 of the group; image columns are 0..pr */                      \
+                    const float dPy = fmaxf(fabsf(HS_DIFF1(ouP.y, uP[r].y)), fabsf(HS_DIFF1(ovP.y, vP[r].y))); \
+                    const float dQx = fmaxf(fabsf(HS_DIFF1(ouQ.x, uQ[r].x)), fabsf(HS_DIFF1(ovQ.x, vQ[r].x))); \
+                    const float dQy = fmaxf(fabsf(HS_DIFF1(ouQ.y, uQ[r].y)), fabsf(HS_DIFF1(ovQ.y, vQ[r].y))); \
                     e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.x, uP[r].x)), fabsf(HS_DIFF1(ovP.x, vP[r].x))));           \
-                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.y, uP[r].y)), fabsf(HS_DIFF1(ovP.y, vP[r].y)))); \
-                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.x, uQ[r].x)), fabsf(HS_DIFF1(ovQ.x, vQ[r].x)))); \
-                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.y, uQ[r].y)), fabsf(HS_DIFF1(ovQ.y, vQ[r].y)))); \
+                    if (pr >= 1) e = fmaxf(e, HS_PAIR_MS_FOLD ? dQx : dPy);                        \
+                    if (pr >= 2) e = fmaxf(e, HS_PAIR_MS_FOLD ? dQy : dQx);                        \
+                    if (pr >= 3) e = fmaxf(e, HS_PAIR_MS_FOLD ? dPy : dQy);                        \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -919,8 +930,10 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     } while (0)
 #define HF_CROSS(S, PE, A, B)                                                                      \
     do {                                                                                           \
-        if (rdist[A] <= last || rdist[B] <= last)                                                  \
-            cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);             \
+        if (rdist[A] <= last || rdist[B] <= last) {                                                \
+            if (HS_PAIR_MS_FOLD) cross_rows_ms<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]); \
+            else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
+        }                                                                                          \
     } while (0)
     // slot of (buffer, wavefront, half): two planes of 32 float4
 #define HF_SLOT(buf, ww, hh) (ex + ((size_t)(((buf) * NW + (ww)) * 2 + (hh)) * 2) * 32)
@@ -961,14 +974,22 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         // as it is done, so that the write drains under the other rows
         const float w0 = uP[0].x; // witness: the published row's u at column x0 before the sweep
         Cross sp, sc;
-        if (rdist[0] <= last) cross_rows<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
+        if (rdist[0] <= last) {
+            if (HS_PAIR_MS_FOLD) cross_rows_ms<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
+            else cross_rows<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int rn = r + 1 < R ? r + 1 : r;
             if (r == R - 1) {
                 if (rdist[r] <= last) {
-                    if (r & 1) cross_rows<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
-                    else cross_rows<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                    if (HS_PAIR_MS_FOLD) {
+                        if (r & 1) cross_rows_ms<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                        else cross_rows_ms<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                    } else {
+                        if (r & 1) cross_rows<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                        else cross_rows<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                    }
                 }
             } else if (r & 1) HF_CROSS(sc, E0 ^ 1, r, rn);
             else HF_CROSS(sc, E0, r, rn);
@@ -1050,8 +1071,13 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                 const int y = yb + (lower ? 2 * R - 1 - r : r);
                 const long long off = base + (long long)y * g.P + x0;
                 const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
-                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
+                if (HS_PAIR_MS_FOLD) { // P = (p0, p3), Q = (p1, p2)
+                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
+                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
+                } else {
+                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
+                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
+                }
             }
         }
     }
