@@ -27,12 +27,6 @@
 #ifndef HS_SWEEP_STAMPS
 #define HS_SWEEP_STAMPS 0
 #endif
-#ifndef HS_PAIR_MS /* strip kernel: a lane's pixels p0..p3 as the register pairs (p0, p3), (p1, p2) instead of (p0, p1), (p2, p3) */
-#define HS_PAIR_MS 1
-#endif
-#ifndef HS_PAIR_MS_FOLD /* the same for the folded kernel */
-#define HS_PAIR_MS_FOLD 1
-#endif
 #ifndef HS_DIAG /* bit mask of diagnostic knobs in the strip sweep (timing experiments only, results are wrong): 1 no LDS
                    exchange, 2 no barrier, 4 no trapezoid gating, 8 no arithmetic */
 #define HS_DIAG 0
@@ -100,8 +94,8 @@ __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, 
 #define HS_DIFF1(o, n) ((o) - (n))
 #endif
 
-// One row of one lane: pixels (p0,p1) = P and (p2,p3) = Q as two register pairs (p0 is an even image column: the
-// region starts at a multiple of 4), so that most arithmetic is packed (2 pixels per v_pk_add/mul/fma_f32).
+// One row of one lane: pixels (p0,p3) = P and (p1,p2) = Q as two register pairs (p0 is an even image column: the
+// region starts at a multiple of 4), so that all arithmetic is packed (2 pixels per v_pk_add/mul/fma_f32; cross_rows).
 struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
 
 // The canonical 4-neighbour sum (update_cv, hs_kernels.hip.h) adds two diagonal pairs chosen by the pixel's
@@ -109,64 +103,14 @@ struct RowCoef { f2 alP, alQ, beP, beQ, gaP, gaQ; };
 //   cross sum of the boundary between rows r and r+1, at pixel i of row r:
 //       s_r[i] = x[r+1][i] + x[r][i+1]   (pixel (r,i) even)        s_r[i] = x[r+1][i] + x[r][i-1]   (odd)
 //   neighbour sum of pixel (r,i):  s_r[i] + s_(r-1)[i-1]  (even)   s_r[i] + s_(r-1)[i+1]  (odd)
-// With E = parity of pixel p0 of the upper row: for E = 0 the cross sum pairs each pixel with the other pixel of
-// its register pair (one packed add with swapped halves) and the neighbour sum reaches over the pair boundary (two
-// DPP adds from the adjacent lanes, two plain adds); for E = 1 it is the other way round.  Rows alternate, so a row
-// costs 2 packed + 2 DPP + 2 plain adds per plane where the straightforward sum costs 4 + 2 + 2.
+// A lane's four pixels p0..p3 of a row live in the two register pairs P = (p0, p3) and Q = (p1, p2).  With E = parity
+// of pixel p0 of the upper row: for E = 0 every pixel's partner lies in the lane's OTHER pair (two plain packed adds);
+// for E = 1 the inner pixels p1, p2 are each other's partners (one packed add with swapped halves) and the outer ones
+// reach into the adjacent lanes (two DPP adds); the neighbour sum is the other way round.  Rows alternate, so a row
+// costs 3 packed + 2 DPP adds per plane and no unpacked one (pairing (p0, p1), (p2, p3): 2 packed + 2 DPP + 2 plain;
+// the straightforward sum: 4 + 2 + 2).
 struct Cross { f2 uP, uQ, vP, vQ; };
 
-// s of the boundary below row `c` (whose side neighbours it uses; `d` is the row underneath), E = parity of c's p0
-template <int E>
-__device__ __forceinline__ void cross_rows(Cross &s, const f2 cuP, const f2 cuQ, const f2 cvP, const f2 cvQ,
-                                           const f2 duP, const f2 duQ, const f2 dvP, const f2 dvQ)
-{
-    if (E == 0) {
-        s.uP = duP + f2_swap(cuP); s.uQ = duQ + f2_swap(cuQ);
-        s.vP = dvP + f2_swap(cvP); s.vQ = dvQ + f2_swap(cvQ);
-    } else {
-        s.uP.x = duP.x + wave_from_prev_lane(cuQ.y); s.uP.y = duP.y + cuQ.x;
-        s.uQ.x = duQ.x + cuP.y;                      s.uQ.y = duQ.y + wave_from_next_lane(cuP.x);
-        s.vP.x = dvP.x + wave_from_prev_lane(cvQ.y); s.vP.y = dvP.y + cvQ.x;
-        s.vQ.x = dvQ.x + cvP.y;                      s.vQ.y = dvQ.y + wave_from_next_lane(cvP.x);
-    }
-}
-
-// One row: neighbour sums from the cross sums below (sc) and above (sp) it, then the update in place.
-// E = parity of the row's p0.  HS_SCALED: the sums ARE the averages at the next scale (file header).
-template <int E>
-__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const Cross &sc, const Cross &sp, RowCoef &c)
-{
-    f2 tP, tQ, sP, sQ;
-    if (E == 0) {
-        tP.x = sc.uP.x + wave_from_prev_lane(sp.uQ.y); tP.y = sc.uP.y + sp.uQ.x;
-        tQ.x = sc.uQ.x + sp.uP.y;                      tQ.y = sc.uQ.y + wave_from_next_lane(sp.uP.x);
-        sP.x = sc.vP.x + wave_from_prev_lane(sp.vQ.y); sP.y = sc.vP.y + sp.vQ.x;
-        sQ.x = sc.vQ.x + sp.vP.y;                      sQ.y = sc.vQ.y + wave_from_next_lane(sp.vP.x);
-    } else {
-        tP = sc.uP + f2_swap(sp.uP); tQ = sc.uQ + f2_swap(sp.uQ);
-        sP = sc.vP + f2_swap(sp.vP); sQ = sc.vQ + f2_swap(sp.vQ);
-    }
-#if HS_SCALED
-    const f2 ubP = tP, ubQ = tQ, vbP = sP, vbQ = sQ; // 4^(k+1) * average
-#else
-    const f2 ubP = tP * 0.25f, ubQ = tQ * 0.25f, vbP = sP * 0.25f, vbQ = sQ * 0.25f;
-#endif
-    const f2 qP = f2_fma(c.alP, ubP, f2_fma(c.beP, vbP, c.gaP));
-    const f2 qQ = f2_fma(c.alQ, ubQ, f2_fma(c.beQ, vbQ, c.gaQ));
-    uP = f2_fma(-c.alP, qP, ubP);
-    vP = f2_fma(-c.beP, qP, vbP);
-    uQ = f2_fma(-c.alQ, qQ, ubQ);
-    vQ = f2_fma(-c.beQ, qQ, vbQ);
-#if HS_SCALED
-    c.gaP *= 4.0f; // the constant term at the next sweep's scale
-    c.gaQ *= 4.0f;
-#endif
-}
-
-// The same two steps for the strip kernel's pairing P = (p0, p3), Q = (p1, p2) (HS_PAIR_MS): where the partner of a pixel
-// is the other pixel of its lane's INNER pair the sum is one packed add with swapped halves, and the outer pixels reach
-// into the adjacent lanes (two DPP adds); where partners lie in the other pair of the lane, two plain packed adds.  A
-// row costs 3 packed + 2 DPP adds per plane (pairing (p0, p1), (p2, p3): 2 packed + 2 DPP + 2 plain).
 // a + swap(b) in one packed add (written out: left to the compiler, the swap of a row that has just come from LDS is
 // done with two moves first)
 __device__ __forceinline__ f2 pk_add_swapped(f2 a, f2 b)
@@ -176,9 +120,10 @@ __device__ __forceinline__ f2 pk_add_swapped(f2 a, f2 b)
     return r;
 }
 
+// s of the boundary below row `c` (whose side neighbours it uses; `d` is the row underneath), E = parity of c's p0
 template <int E>
-__device__ __forceinline__ void cross_rows_ms(Cross &s, const f2 cuP, const f2 cuQ, const f2 cvP, const f2 cvQ,
-                                              const f2 duP, const f2 duQ, const f2 dvP, const f2 dvQ)
+__device__ __forceinline__ void cross_rows(Cross &s, const f2 cuP, const f2 cuQ, const f2 cvP, const f2 cvQ,
+                                           const f2 duP, const f2 duQ, const f2 dvP, const f2 dvQ)
 {
     if (E == 0) { // p0 + c1, p3 + c2 | p1 + c0, p2 + c3
         s.uP = duP + cuQ; s.uQ = duQ + cuP;
@@ -191,8 +136,10 @@ __device__ __forceinline__ void cross_rows_ms(Cross &s, const f2 cuP, const f2 c
     }
 }
 
+// One row: neighbour sums from the cross sums below (sc) and above (sp) it, then the update in place.
+// E = parity of the row's p0.  HS_SCALED: the sums ARE the averages at the next scale (file header).
 template <int E>
-__device__ __forceinline__ void strip_row_update_ms(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const Cross &sc, const Cross &sp, RowCoef &c)
+__device__ __forceinline__ void strip_row_update(f2 &uP, f2 &uQ, f2 &vP, f2 &vQ, const Cross &sc, const Cross &sp, RowCoef &c)
 {
     f2 tP, tQ, sP, sQ;
     if (E == 0) {
@@ -431,8 +378,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     for (int r = 0; r < R; r++) {
         const float4 lu_ = lu[r], lv_ = lv[r];
         const uint4 cw = lc[r];
-        // pairing of the lane's pixels p0..p3 into the register pairs P, Q: (p0, p3), (p1, p2) (HS_PAIR_MS; see cross_rows_ms)
-        constexpr int iPx = 0, iPy = HS_PAIR_MS ? 3 : 1, iQx = HS_PAIR_MS ? 1 : 2, iQy = HS_PAIR_MS ? 2 : 3;
+        // the lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows)
+        constexpr int iPx = 0, iPy = 3, iQx = 1, iQy = 2;
         const float lu4[4] = {lu_.x, lu_.y, lu_.z, lu_.w}, lv4[4] = {lv_.x, lv_.y, lv_.z, lv_.w};
         uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
         vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
@@ -471,7 +418,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             f2 ouP, ouQ, ovP, ovQ;                                                                 \
             if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
             if (HS_DIAG & 8) uP[r] += SC.uP + SP.uP;                                               \
-            else if (HS_PAIR_MS) strip_row_update_ms<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]); \
             else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
             if (EM == 1) {                                                                         \
                 if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
@@ -482,14 +428,11 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                         e = fmaxf(fmaxf(e, fabsf(dVP.x)), fabsf(dVP.y));                           \
                         e = fmaxf(fmaxf(e, fabsf(dVQ.x)), fabsf(dVQ.y));                           \
                     } else {                                                                       \
-                        /* pixels p0..p3 of the group; image columns are 0..pr */                \
-                        const float d1 = HS_PAIR_MS ? fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)) : fmaxf(fabsf(dUP.y), fabsf(dVP.y)); \
-                        const float d2 = HS_PAIR_MS ? fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)) : fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)); \
-                        const float d3 = HS_PAIR_MS ? fmaxf(fabsf(dUP.y), fabsf(dVP.y)) : fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)); \
+                        /* image columns of the group are p0 .. p(pr); P = (p0, p3), Q = (p1, p2) */ \
                         e = fmaxf(e, fmaxf(fabsf(dUP.x), fabsf(dVP.x)));                           \
-                        if (pr >= 1) e = fmaxf(e, d1);                                             \
-                        if (pr >= 2) e = fmaxf(e, d2);                                             \
-                        if (pr >= 3) e = fmaxf(e, d3);                                             \
+                        if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(dUQ.x), fabsf(dVQ.x)));              \
+                        if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(dUQ.y), fabsf(dVQ.y)));              \
+                        if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(dUP.y), fabsf(dVP.y)));              \
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
@@ -500,7 +443,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     do {                                                                                           \
         if (HS_ACT(A) || HS_ACT(B)) {                                                              \
             if (HS_DIAG & 8) S.uP = uP[A] + uP[B];                                                 \
-            else if (HS_PAIR_MS) cross_rows_ms<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]); \
             else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
         }                                                                                          \
     } while (0)
@@ -582,15 +524,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         float w0 = 0.f;
         if (wturn) w0 = uP[0].x; // witness: u at column x0 of register row 0 before the sweep
         // --- first row (the strip's upper edge)
-        if (HS_ACT(0)) {
-            if (HS_PAIR_MS) cross_rows_ms<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
-            else cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
-        }
+        if (HS_ACT(0)) cross_rows<E0 ^ 1>(sA, huP, huQ, hvP, hvQ, uP[0], uQ[0], vP[0], vQ[0]);
         if (R == 1) {
-            if (HS_ACT(0)) {
-                if (HS_PAIR_MS) cross_rows_ms<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
-                else cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
-            }
+            if (HS_ACT(0)) cross_rows<E0>(s0, uP[0], uQ[0], vP[0], vQ[0], duP, duQ, dvP, dvQ);
         } else {
             constexpr int R1 = R > 1 ? 1 : 0;
             HS_CROSS(s0, E0, 0, R1);
@@ -605,10 +541,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         if (R >= 2) {
             // --- last row (the lower edge), then both edges go to the other wavefronts
             constexpr int RM = R > 2 ? R - 2 : 0;
-            if (HS_ACT(R - 1)) {
-                if (HS_PAIR_MS) cross_rows_ms<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
-                else cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
-            }
+            if (HS_ACT(R - 1)) cross_rows<EL>(sL, uP[R - 1], uQ[R - 1], vP[R - 1], vQ[R - 1], duP, duQ, dvP, dvQ);
                 if (R >= 3) HS_CROSS(sK, EL ^ 1, RM, R - 1);
             if (R == 2) HS_ROW(R - 1, EL, sL, s0);
             else HS_ROW(R - 1, EL, sL, sK);
@@ -704,13 +637,9 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                 const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
                 // (non-temporal and agent-scope write-through stores were tried here: both slower)
                 const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
-                if (HS_PAIR_MS) { // P = (p0, p3), Q = (p1, p2)
-                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
-                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
-                } else {
-                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
-                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
-                }
+                // P = (p0, p3), Q = (p1, p2)
+                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
             }
         }
     }
@@ -872,8 +801,8 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     if (DERIV) strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        // pairing of the lane's pixels p0..p3 into the register pairs P, Q: (p0, p3), (p1, p2) (HS_PAIR_MS_FOLD; see cross_rows_ms)
-        constexpr int iPx = 0, iPy = HS_PAIR_MS_FOLD ? 3 : 1, iQx = HS_PAIR_MS_FOLD ? 1 : 2, iQy = HS_PAIR_MS_FOLD ? 2 : 3;
+        // the lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows)
+        constexpr int iPx = 0, iPy = 3, iQx = 1, iQy = 2;
         const float lu4[4] = {lu[r].x, lu[r].y, lu[r].z, lu[r].w}, lv4[4] = {lv[r].x, lv[r].y, lv[r].z, lv[r].w};
         uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
         vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
@@ -911,18 +840,14 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         if (rdist[r] <= last) {                                                                    \
             f2 ouP, ouQ, ovP, ovQ;                                                                 \
             if (EM == 1) { ouP = uP[r]; ouQ = uQ[r]; ovP = vP[r]; ovQ = vQ[r]; }                   \
-            if (HS_PAIR_MS_FOLD) strip_row_update_ms<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]); \
-            else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
+            strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                       \
             if (EM == 1) {                                                                         \
                 if (((rowcore >> (r)) & 1u) && lanecore) {                                         \
-                    /* pixels p0..p3 of the group; image columns are 0..pr */                      \
-                    const float dPy = fmaxf(fabsf(HS_DIFF1(ouP.y, uP[r].y)), fabsf(HS_DIFF1(ovP.y, vP[r].y))); \
-                    const float dQx = fmaxf(fabsf(HS_DIFF1(ouQ.x, uQ[r].x)), fabsf(HS_DIFF1(ovQ.x, vQ[r].x))); \
-                    const float dQy = fmaxf(fabsf(HS_DIFF1(ouQ.y, uQ[r].y)), fabsf(HS_DIFF1(ovQ.y, vQ[r].y))); \
+                    /* image columns of the group are p0 .. p(pr); P = (p0, p3), Q = (p1, p2) */   \
                     e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.x, uP[r].x)), fabsf(HS_DIFF1(ovP.x, vP[r].x))));           \
-                    if (pr >= 1) e = fmaxf(e, HS_PAIR_MS_FOLD ? dQx : dPy);                        \
-                    if (pr >= 2) e = fmaxf(e, HS_PAIR_MS_FOLD ? dQy : dQx);                        \
-                    if (pr >= 3) e = fmaxf(e, HS_PAIR_MS_FOLD ? dPy : dQy);                        \
+                    if (pr >= 1) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.x, uQ[r].x)), fabsf(HS_DIFF1(ovQ.x, vQ[r].x)))); \
+                    if (pr >= 2) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouQ.y, uQ[r].y)), fabsf(HS_DIFF1(ovQ.y, vQ[r].y)))); \
+                    if (pr >= 3) e = fmaxf(e, fmaxf(fabsf(HS_DIFF1(ouP.y, uP[r].y)), fabsf(HS_DIFF1(ovP.y, vP[r].y)))); \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -930,10 +855,8 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     } while (0)
 #define HF_CROSS(S, PE, A, B)                                                                      \
     do {                                                                                           \
-        if (rdist[A] <= last || rdist[B] <= last) {                                                \
-            if (HS_PAIR_MS_FOLD) cross_rows_ms<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]); \
-            else cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);        \
-        }                                                                                          \
+        if (rdist[A] <= last || rdist[B] <= last)                                                  \
+            cross_rows<PE>(S, uP[A], uQ[A], vP[A], vQ[A], uP[B], uQ[B], vP[B], vQ[B]);             \
     } while (0)
     // slot of (buffer, wavefront, half): two planes of 32 float4
 #define HF_SLOT(buf, ww, hh) (ex + ((size_t)(((buf) * NW + (ww)) * 2 + (hh)) * 2) * 32)
@@ -974,22 +897,14 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         // as it is done, so that the write drains under the other rows
         const float w0 = uP[0].x; // witness: the published row's u at column x0 before the sweep
         Cross sp, sc;
-        if (rdist[0] <= last) {
-            if (HS_PAIR_MS_FOLD) cross_rows_ms<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
-            else cross_rows<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
-        }
+        if (rdist[0] <= last) cross_rows<E0 ^ 1>(sp, ouP_, ouQ_, ovP_, ovQ_, uP[0], uQ[0], vP[0], vQ[0]);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int rn = r + 1 < R ? r + 1 : r;
             if (r == R - 1) {
                 if (rdist[r] <= last) {
-                    if (HS_PAIR_MS_FOLD) {
-                        if (r & 1) cross_rows_ms<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
-                        else cross_rows_ms<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
-                    } else {
-                        if (r & 1) cross_rows<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
-                        else cross_rows<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
-                    }
+                    if (r & 1) cross_rows<E0 ^ 1>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
+                    else cross_rows<E0>(sc, uP[r], uQ[r], vP[r], vQ[r], iuP, iuQ, ivP, ivQ);
                 }
             } else if (r & 1) HF_CROSS(sc, E0 ^ 1, r, rn);
             else HF_CROSS(sc, E0, r, rn);
@@ -1071,13 +986,9 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                 const int y = yb + (lower ? 2 * R - 1 - r : r);
                 const long long off = base + (long long)y * g.P + x0;
                 const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
-                if (HS_PAIR_MS_FOLD) { // P = (p0, p3), Q = (p1, p2)
-                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
-                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
-                } else {
-                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uP[r].y * fin, uQ[r].x * fin, uQ[r].y * fin);
-                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vP[r].y * fin, vQ[r].x * fin, vQ[r].y * fin);
-                }
+                // P = (p0, p3), Q = (p1, p2)
+                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
+                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
             }
         }
     }
