@@ -255,7 +255,8 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
                 // operations where both operands are register pairs (the edge term, the weights, the update): -15 % per
                 // solve.  (Holding a lane's pixels as the pairs (p0, p3), (p1, p2) makes the L+R sums and the carried sums
                 // packed as well -- 8 instructions fewer per row -- but measured no faster at 512 threads and slower at
-                // 1024, where it spills: not kept.)
+                // 1024, where it spills: not kept.  Nor was keeping every window in the shifted pairs (l, p0), (p1, p2),
+                // (p3, r) too (v_pk_mov_b32), which packs the L+R sums and the corner term: the moves eat the saving.)
                 const f2c k6 = f2c{c6, c6}, k12 = f2c{c12, c12};
                 const f2c euA = peuA + f2c{Nu.c0, Nu.c1}, euB = peuB + f2c{Nu.c2, Nu.c3};
                 const f2c evA = pevA + f2c{Nv.c0, Nv.c1}, evB = pevB + f2c{Nv.c2, Nv.c3};
