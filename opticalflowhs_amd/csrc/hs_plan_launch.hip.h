@@ -61,7 +61,7 @@ hipError_t launch_fused_t(const hsflow_ctx *c, const FusedPlan &p, const float *
                           float *uo, float *vo, float coeff, bool configure_only)
 {
     auto kern = hsk::k_jacobi_fused<NT, K, EPS, LR>;
-    static bool configured[64] = {}; // per instantiation and device: raise the dynamic-LDS cap once
+    static std::atomic<bool> configured[64]; // per instantiation and device: raise the dynamic-LDS cap once (several host threads may get here)
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
@@ -102,7 +102,7 @@ hipError_t launch_classic_fused_t(const hsflow_ctx *c, const FusedPlan &p, bool 
                                   float *uo, float *vo, float alpha2, bool configure_only)
 {
     auto kern = write_v ? hsk::k_jacobi_classic_fused<NT, K, true> : hsk::k_jacobi_classic_fused<NT, K, false>;
-    static bool configured[2][64] = {};
+    static std::atomic<bool> configured[2][64];
     if (p.lds_bytes > 32 * 1024 && !configured[write_v][c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
@@ -232,7 +232,7 @@ hipError_t launch_classic_strip_t(const hsflow_ctx *c, const ClassicStripPlan &p
     const bool ghost = (p.g.W & 3) != 0;
     auto kern = write_v ? (ghost ? hsk::k_classic_strip<R, NTMAX, true, true> : hsk::k_classic_strip<R, NTMAX, true, false>)
                         : (ghost ? hsk::k_classic_strip<R, NTMAX, false, true> : hsk::k_classic_strip<R, NTMAX, false, false>);
-    static bool configured[4][64] = {};
+    static std::atomic<bool> configured[4][64];
     const int ki = (write_v ? 2 : 0) + (ghost ? 1 : 0);
     if (p.lds_bytes > 32 * 1024 && !configured[ki][c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -366,7 +366,7 @@ hipError_t launch_strip_te(const hsflow_ctx *c, const StripPlan &p, const float 
         if constexpr (FOLD) return hsk::k_jacobi_fold<R, NTMAX, EPS, E0>;
         else return hsk::k_jacobi_strip<R, NTMAX, EPS, E0>;
     }();
-    static bool configured[64] = {};
+    static std::atomic<bool> configured[64];
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
@@ -426,7 +426,7 @@ hipError_t launch_strip_deriv_te(const hsflow_ctx *c, const StripPlan &p, const 
         if constexpr (FOLD) return hsk::k_jacobi_fold_deriv<R, NTMAX, EPS, E0>;
         else return hsk::k_jacobi_strip_deriv<R, NTMAX, EPS, E0>;
     }();
-    static bool configured[64] = {};
+    static std::atomic<bool> configured[64];
     if (p.lds_bytes > 32 * 1024 && !configured[c->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);

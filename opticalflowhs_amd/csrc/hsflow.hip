@@ -11,6 +11,7 @@
 #include "hs_kernels_classic.hip.h"
 #include "hs_kernels_classic_strip.hip.h"
 
+#include <atomic>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>

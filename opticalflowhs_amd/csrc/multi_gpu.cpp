@@ -85,7 +85,11 @@ void worker_fail(Worker *w, int st, const char *what)
 // (upload, solve and download of neighbouring pairs overlap there) and retires the oldest when it runs dry or full.
 void worker_main(Worker *w)
 {
-    hipSetDevice(w->device);
+    if (hipSetDevice(w->device) != hipSuccess) {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->status = HSFLOW_E_DEVICE;
+        w->err = "hipSetDevice failed in the worker thread of device " + std::to_string(w->device);
+    }
     const int depth = hsflow_pipeline_depth(w->pl);
     for (;;) {
         Job job;
@@ -102,7 +106,9 @@ void worker_main(Worker *w)
         }
         if (have) {
             uint64_t pt = 0;
-            const int st = hsflow_pipeline_submit_ex(w->pl, job.format, job.prev, job.ps, job.curr, job.cs, job.u, job.us, job.v, job.vs,
+            bool dead;
+            { std::lock_guard<std::mutex> lk(w->mu); dead = w->status == HSFLOW_E_DEVICE && w->err.rfind("hipSetDevice", 0) == 0; }
+            const int st = dead ? HSFLOW_E_DEVICE : hsflow_pipeline_submit_ex(w->pl, job.format, job.prev, job.ps, job.curr, job.cs, job.u, job.us, job.v, job.vs,
                                                      &job.params, &pt);
             std::lock_guard<std::mutex> lk(w->mu);
             if (st) worker_fail(w, st, "hsflow_pipeline_submit_ex");
@@ -233,7 +239,9 @@ struct Slab {
     // staging rows for the exchange, on this slab's device: what it sends up / down and what it receives from above / below
     float *send_up = nullptr, *send_dn = nullptr, *recv_up = nullptr, *recv_dn = nullptr; // each: 2 planes x halo rows x W
     hipEvent_t sent_up = nullptr, sent_dn = nullptr; // this slab's rows for the neighbour above / below are in its send buffer
-    hipEvent_t took_up = nullptr, took_dn = nullptr; // the neighbour above / below has copied them out (buffer free again)
+    // the neighbour above / below has copied them out (buffer free again).  Recorded on the NEIGHBOUR's stream, so they
+    // are created on the neighbour's device (an event can only be recorded on a stream of the device it was created on)
+    hipEvent_t took_up = nullptr, took_dn = nullptr;
     bool took_up_valid = false, took_dn_valid = false;
 };
 
@@ -343,7 +351,18 @@ int hsflow_slab_create(hsflow_slab **out, const int *devices, int nslab, int wid
         const size_t bytes = (size_t)2 * halo * width * sizeof(float);
         if (k > 0) { SL_TRY(hipMalloc((void **)&sl.send_up, bytes)); SL_TRY(hipMalloc((void **)&sl.recv_up, bytes)); }
         if (k + 1 < nslab) { SL_TRY(hipMalloc((void **)&sl.send_dn, bytes)); SL_TRY(hipMalloc((void **)&sl.recv_dn, bytes)); }
-        for (hipEvent_t *e : {&sl.sent_up, &sl.sent_dn, &sl.took_up, &sl.took_dn}) SL_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&sl.sent_up, &sl.sent_dn}) SL_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    for (int k = 0; k < nslab; k++) { // "taken" events live on the device of the slab that does the taking
+        Slab &sl = s->slabs[(size_t)k];
+        if (k > 0) {
+            SL_TRY(hipSetDevice(s->slabs[(size_t)k - 1].device));
+            SL_TRY(hipEventCreateWithFlags(&sl.took_up, hipEventDisableTiming));
+        }
+        if (k + 1 < nslab) {
+            SL_TRY(hipSetDevice(s->slabs[(size_t)k + 1].device));
+            SL_TRY(hipEventCreateWithFlags(&sl.took_dn, hipEventDisableTiming));
+        }
     }
     // peer access between neighbouring slabs on different GPUs (xGMI); without it the runtime stages the copy
     for (int k = 0; k + 1 < nslab; k++) {
