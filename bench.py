@@ -12,7 +12,9 @@ the elapsed time.  For N > 1 two more measurements ride in the same JSON line (e
 (BASELINE config C4: 512 host-resident pairs over the ranks through the pair pipeline, PCIe included) and
 `c5_slab` (config C5: one 16384^2 frame in row slabs, halo rows exchanged with RCCL send/recv).
 
-Launch: python bench.py [--gpus 1]   or, for N > 1,
+Launch: python bench.py [--gpus N]   (for N > 1 without WORLD_SIZE in the environment this process starts the N
+        ranks itself -- fresh child processes under torch.distributed.run, before anything here touches the GPU --
+        relays rank 0's JSON line and exits with the children's status), or, as the driver does for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -182,8 +184,26 @@ def run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barri
     return out
 
 
+def self_launch(args):
+    """--gpus N > 1 started as a plain `python bench.py`: run the N ranks as children of a torch.distributed.run
+    child (nothing in THIS process has touched torch or the GPU yet), pass their output through and return their
+    exit status.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's hosts support dmabuf IPC only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 

@@ -77,6 +77,23 @@ def test_bench_two_ranks_rehearsal(gpu_ok):
     assert c5["plain"]["exchanges"] == 4 and c5["overlap"]["exchanges"] == 4 and c5["plain"]["value"] > 0 and c5["overlap"]["value"] > 0
 
 
+def test_bench_gpus_2_launches_its_own_ranks(gpu_ok):
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE (how the driver starts the N = 1 run; if the
+    SCALE run is started the same way it must not die before measuring): bench.py starts the two ranks itself and
+    relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSFLOW_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--c4-pairs", "16", "--c5-size", "2048", "--c5-iters", "70", "--c5-halo", "16"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert "c4_pipeline" in d and "c5_slab" in d and d["c5_slab"]["owned_rows_bit_identical_to_band_solve"] is True
+    for k in KEYS:
+        assert k in d, k
+
+
 @pytest.mark.parametrize("extra", [[], ["--overlap"]])
 def test_slab_two_ranks_rehearsal_is_bit_identical(gpu_ok, extra):
     """tools/bench_slab.py with two ranks sharing the card (gloo, halo rows staged through the host): the
