@@ -79,6 +79,16 @@ extern "C" {
                                   its folded form below ~1.5 Mpixel per context)              */
 #define HSFLOW_KERNEL_FOLD 4   /* as STRIP, two 128-column strips per wavefront (half the LDS
                                   exchange; inner boundary swapped in registers)              */
+#define HSFLOW_KERNEL_PERSIST 5 /* STRIP as ONE launch per solve: workgroups keep their tile in registers across
+                                  phases of `fuse_steps` iterations and swap halos through HBM, ordered by per-tile
+                                  phase counters (replaces the host loop HSOpticalFlowOpenCL.cpp:748-752 inside one
+                                  kernel).  Needs every workgroup resident at once: one tile per CU at most, width
+                                  a multiple of 4, ITER or asynchronous ITER|EPS, and the context must be the only one alive on its
+                                  device (two persistent grids could starve each other; every wait inside is bounded
+                                  and a timed-out solve is repeated launch by launch).  On request only: a phase
+                                  boundary measures as dear as a kernel boundary, so AUTO keeps STRIP.
+                                  HSFLOW_E_SIZE when it cannot run.  hsflow_info.kernel reports STRIP,
+                                  hsflow_info.persistent the number of phases.                                  */
 
 typedef struct hsflow_ctx hsflow_ctx;
 
@@ -126,6 +136,8 @@ typedef struct hsflow_info {
                                  and the solve was repeated with Eps measured in every sweep */
     int32_t deriv_fused;      /* 1 if the derivative pass ran inside the first Jacobi launch of the
                                  last solve instead of as a kernel of its own                    */
+    int32_t persistent;       /* phases of the one persistent launch the last solve ran as
+                                 (HSFLOW_KERNEL_PERSIST), 0 for a launch per `fuse_steps` iterations */
 } hsflow_info;
 
 /* --- lifecycle ---------------------------------------------------------------------------- */

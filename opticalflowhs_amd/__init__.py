@@ -5,7 +5,7 @@ mirror of the reference interface; pipeline.py streams pairs through one GPU wit
 no CPU fallback: importing it without libhsflow.so raises.
 """
 from . import _lib
-from ._lib import (HsflowError, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED, MODE_CV,
+from ._lib import (HsflowError, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD, KERNEL_PERSIST, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED, MODE_CV,
                    TERM_EPS, TERM_ITER)
 from .solver import HSFlow, TermCriteria, calc_optical_flow_hs, make_params, plan_query, term_criteria
 from .pipeline import PairPipeline, pinned_empty
@@ -13,7 +13,7 @@ from .multi import MultiPairs, SlabFrame
 
 __all__ = ["HSFlow", "PairPipeline", "MultiPairs", "SlabFrame", "pinned_empty", "make_params", "plan_query", "TermCriteria", "term_criteria", "calc_optical_flow_hs", "HsflowError",
            "TERM_ITER", "TERM_EPS", "MODE_CV", "MODE_CLASSIC", "MODE_CLASSIC_AS_SHIPPED", "KERNEL_AUTO", "KERNEL_SIMPLE",
-           "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD", "OP_SLOTS_PER_PIXEL_SWEEP"]
+           "KERNEL_FUSED", "KERNEL_STRIP", "KERNEL_FOLD", "KERNEL_PERSIST", "OP_SLOTS_PER_PIXEL_SWEEP"]
 
 # Wave64 VALU lane-operations one pixel costs per Jacobi sweep in the multi-sweep kernels' arithmetic (csrc/hs_kernels_strip.hip.h,
 # cross_rows + strip_row_update): 2 + 2 additions for the two neighbour sums (one shared diagonal cross sum and one combining

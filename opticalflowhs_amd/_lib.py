@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("HSFLOW_LIB_PATH") or os.path.join(HERE, "libhsflow.so
 OK, E_ARG, E_SIZE, E_DEVICE, E_OOM, E_STATE, E_NOTERM = range(7)
 TERM_ITER, TERM_EPS = 1, 2
 MODE_CV, MODE_CLASSIC, MODE_CLASSIC_AS_SHIPPED = 0, 1, 2
-KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP, KERNEL_FOLD = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_FUSED, KERNEL_STRIP, KERNEL_FOLD, KERNEL_PERSIST = 0, 1, 2, 3, 4, 5
 FRAMES_GRAY8, FRAMES_GRAY8_BLUR, FRAMES_BGR8, FRAMES_BGR8_BLUR = 0, 1, 2, 3
 
 
@@ -39,7 +39,7 @@ class HsflowInfo(ctypes.Structure):
                 ("lds_bytes", ctypes.c_int32), ("jacobi_launches", ctypes.c_int32),
                 ("deriv_ms", ctypes.c_float), ("jacobi_ms", ctypes.c_float),
                 ("solve_ms", ctypes.c_float), ("eps_rerun", ctypes.c_int32),
-                ("deriv_fused", ctypes.c_int32)]
+                ("deriv_fused", ctypes.c_int32), ("persistent", ctypes.c_int32)]
 
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t

@@ -72,6 +72,17 @@ struct hsflow_ctx {
     unsigned *dEpsTiles = nullptr; // per-sweep, per-workgroup Eps of the launches of one solve
     size_t epsTilesCap = 0;
     float *dUb = nullptr, *dVb = nullptr; // backup of the starting flow (ITER|EPS with use_previous)
+    // the persistent launch (HSFLOW_KERNEL_PERSIST, hs_kernels_strip.hip.h): a third flow buffer (its phases alternate
+    // between this one and the ping-pong buffer the result lands in; the starting flow stays intact), the tiles' phase
+    // counters, the error word (page-locked, device-visible)
+    float *dUp = nullptr, *dVp = nullptr;
+    unsigned *dFlags = nullptr;
+    unsigned *hErr = nullptr, *hErrDev = nullptr;
+    int persist_tiles = 0;       // grid the phase counters are consistent for (0: to be cleared before the next launch)
+    bool persist_off = false;    // a persistent launch timed out on this context: not used again
+    bool persist_unchecked = false; // an asynchronous persistent solve whose error word has not been looked at yet
+    bool counted = false;        // this context is in g_live_ctx
+    int num_cu = 0;              // compute units of the device (one workgroup of the persistent launch per CU)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;
     int cur = 0;                // which of dU/dV holds the current flow
@@ -93,6 +104,7 @@ struct hsflow_ctx {
         JPlan plan;
         int in = 0, zero_in = 0;
         float coeff = 0.f, eps_thr = 0.f;
+        bool from_third = false; // its input lies in dUp / dVp (last phase of a persistent launch), not the other ping-pong buffer
     } lastl;
     bool force_exact = false; // the exact per-sweep pass is wanted (set while a pending solve is settled)
     std::map<GraphKey, GraphEntry> graphs;
@@ -100,6 +112,11 @@ struct hsflow_ctx {
 };
 
 namespace {
+
+// live contexts per device (this process): the persistent launch wants the device to itself -- two persistent grids
+// from two contexts could each hold part of the CUs and wait for workgroups that cannot start
+std::atomic<int> g_live_ctx[64];
+constexpr int kMaxPersistTiles = 4096;
 
 hsflow_ctx *g_oneshot = nullptr; // context kept by hsflow_calc_optical_flow_hs_8u32f between calls
 std::mutex g_oneshot_mutex;

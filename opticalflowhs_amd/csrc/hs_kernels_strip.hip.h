@@ -82,6 +82,50 @@ __device__ __forceinline__ int mirror_index(int i, int n)
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// The persistent form of the strip kernel (k_jacobi_strip_persist): ONE launch for a whole solve.  Every workgroup
+// keeps its region's coefficients and flow in registers across PHASES of T sweeps; between two phases it publishes its
+// core tile (write-through stores), raises its tile's phase counter, waits for the counters of its 8 neighbours and
+// reloads only the halo pixels of its region -- no kernel boundary, no second read of the coefficients, no second
+// v_rsq per pixel.  Replaces the host loop of HSOpticalFlowOpenCL.cpp:748-752 at the level of one kernel.
+// Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table): every byte handed over
+// is stored with `sc1` (write-through) and loaded with `sc1` (L1 bypass); every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane then stores the counter `sc1`; the consumer polls
+// with `sc1` loads from one wave and the other waves load after a workgroup barrier that wave joins.
+// All workgroups must be resident at once (the host checks occupancy x CUs >= grid); every wait is bounded in time:
+// a workgroup that gives up writes the error word and an abort word the others watch, and returns.
+// ------------------------------------------------------------------------------------------
+struct PersistArgs {
+    unsigned *flags;        // [tiles] phases published by each tile, counted up across solves; [tiles] = abort word
+    unsigned *err;          // error word in page-locked host memory: 1 = a wait timed out (results invalid)
+    float *ub[2], *vb[2];   // phase p publishes into buffer p & 1; the last phase's buffer is the solve's output
+    int n_phase, T_last;    // phases of the solve; sweeps of the last one (all others run g.T)
+    unsigned wait_ticks;    // a wait gives up after this many 100 MHz ticks
+};
+
+// The hand-off's 16-byte accesses as raw buffer instructions with the sc1 bit (aux 16: write-through store, L1-bypassing
+// load): the address is a scalar row offset + a per-lane byte offset, so no 64-bit vector arithmetic, and -- unlike
+// inline assembly -- the compiler keeps track of the loads in flight.  One descriptor per plane (no bounds: the
+// offsets are those of the ordinary loads and stores).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(float *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ void store_f4_sc1(__amdgpu_buffer_rsrc_t rs, unsigned row_bytes, unsigned lane_bytes, f4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rs, (int)lane_bytes, (int)row_bytes, 16);
+}
+__device__ __forceinline__ f4 load_f4_sc1(__amdgpu_buffer_rsrc_t rs, unsigned row_bytes, unsigned lane_bytes)
+{
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)row_bytes, 16));
+}
+__device__ __forceinline__ unsigned load_u32_sc1(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
@@ -254,7 +298,7 @@ __device__ __forceinline__ void strip_derive(const uint8_t *__restrict__ fA, con
     }
 }
 
-template <int R, int NTMAX, int EPS, int E0, bool DERIV>
+template <int R, int NTMAX, int EPS, int E0, bool DERIV, bool PERSIST = false>
 __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         const float *__restrict__ u_in,
                                                         const float *__restrict__ v_in,
@@ -264,8 +308,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
                                                         unsigned *__restrict__ eps_out, const int eps_stride,
                                                         unsigned long long *__restrict__ stamps,
                                                         const float eps_thr, const uint8_t *__restrict__ fA,
-                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w)
+                                                        const uint8_t *__restrict__ fB, uint32_t *__restrict__ coef_w,
+                                                        const PersistArgs pa = PersistArgs())
 {
+    static_assert(!PERSIST || EPS == 0 || EPS == 2, "the persistent form runs plain or witness phases");
     // EPS == 1: eps_out[sweep * eps_stride + workgroup] receives that workgroup's max |new - old| over
     // its core pixels (plain stores, no atomics; the host reduces over the workgroups afterwards).
     // EPS == 2 ("witness"): the cheap way to PROVE that no sweep of this launch had Eps < epsilon.
@@ -459,8 +505,6 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     // Sweep s reads buffer s&1 and publishes its new edge rows into buffer (s+1)&1, then meets the
     // other wavefronts at ONE barrier.  The edge rows are updated and published FIRST so that the
     // LDS writes drain while the interior rows are being computed.
-    HS_PUBLISH(0);
-    __syncthreads();
     if (stamps) st1 = __builtin_amdgcn_s_memtime();
     // Whose slot is the row above register row 0 (wu, su) and the row below register row R-1 (wd, sd)?  A strip's
     // bottom image row is its register row R-1 (slot pair 2) unless it is reversed (then row 0: slot pair 0), its
@@ -483,7 +527,11 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     const int wit_lo = (g.T + R - 1) / R, wit_n = (g.T + core_here) / R - wit_lo; // wavefronts wit_lo .. wit_lo + wit_n - 1
     const bool wit_rot = wit_n > 0;
     const int wit_per = wit_rot ? wit_n : 1;
-    int wit_cnt = !wit_rot ? 0 : (w >= wit_lo && w < wit_lo + wit_n) ? w - wit_lo : (1 << 30);
+    const int wit_cnt0 = !wit_rot ? 0 : (w >= wit_lo && w < wit_lo + wit_n) ? w - wit_lo : (1 << 30);
+    int wit_cnt = wit_cnt0;
+    // Sweeps of the current phase: the launch's T, except in the last phase of a persistent launch (PERSIST).  A shorter
+    // phase simply starts further down the trapezoid: rows further than Tp - 1 from the core are never swept.
+    int Tp = g.T;
     // One sweep.  EM is the Eps mode of THIS sweep: the launch's own (EPS 0, 1, 2), or for EPS == 3 witness
     // (2) in all sweeps but the last and measured (1) in the last -- a second copy of the sweep code after the
     // loop, so that the loop keeps the registers of the witness kernel.  E0 = parity of pixel p0 of register
@@ -498,7 +546,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #if HS_DIAG & 4 /* diagnostic build: every row swept in every sweep (no trapezoid) */
         const int last = 1 << 20;
 #else
-        const int last = g.T - 1 - s; // rows with rdist <= last are still swept
+        const int last = Tp - 1 - s; // rows with rdist <= last are still swept
 #endif
         // HS_SCALED: this sweep takes the flow from scale 4^s to 4^(s+1)
         const float unscale = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * (s + 1)) : 1.0f;
@@ -547,7 +595,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             else HS_ROW(R - 1, EL, sL, sK);
         }
 #if !(HS_DIAG & 1)
-        if (s + 1 < g.T) HS_PUBLISH((s + 1) & 1);
+        if (s + 1 < Tp) HS_PUBLISH((s + 1) & 1);
 #endif
         // --- interior rows, top to bottom: each needs the cross sum above it (kept) and the one below (new)
         if (R >= 3) {
@@ -580,7 +628,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             }
         }
 #if !(HS_DIAG & 2) /* diagnostic build: no barrier */
-        if (s + 1 < g.T) __syncthreads();
+        if (s + 1 < Tp) __syncthreads();
 #endif
         // diagnostic (stamps != NULL only): when each sweep ended -- all wavefronts leave the barrier together, so
         // wavefront 0 sees the workgroup's sweep times; slots behind the 8 phase stamps of every workgroup
@@ -589,60 +637,186 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 32 + (s & 31)] = __builtin_amdgcn_s_memtime();
 #endif
     };
+    // PERSIST: the phases of the solve; otherwise one pass (the `break` after the store is unconditional).
+    int ph = 0;
+    unsigned flag_base = 0; // this tile's phase counter at the start of the launch (all tiles agree; wavefront 0 only)
+    unsigned long long pt_sweep = 0, pt_pub = 0, pt_wait = 0, pt_load = 0, pt0 = 0, pt_first = 0; // PERSIST diagnostics (stamps)
+    if constexpr (PERSIST) {
+        if (w == 0) flag_base = (unsigned)__builtin_amdgcn_readfirstlane((int)load_u32_sc1(pa.flags + tile));
+    }
+#pragma unroll 1
+    for (;;) {
+    if constexpr (PERSIST) {
+        Tp = ph == pa.n_phase - 1 ? pa.T_last : g.T;
+        seen_n = 0;
+        wit_cnt = wit_cnt0;
+        if (stamps && ph == 0) pt_first = pt0 = __builtin_amdgcn_s_memtime();
+    }
+    HS_PUBLISH(0);
+    __syncthreads();
+    if (PERSIST && stamps && ph > 0) { // (the reloaded rows are first used by the publish above: their latency belongs to the reload)
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        pt_load += t - pt0;
+        pt0 = t;
+    }
     if constexpr (EPS == 3) {
 #pragma unroll 1
-        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, 2>{});
-        sweep(g.T - 1, std::integral_constant<int, 1>{});
+        for (int s = 0; s + 1 < Tp; s++) sweep(s, std::integral_constant<int, 2>{});
+        sweep(Tp - 1, std::integral_constant<int, 1>{});
     } else if constexpr (HS_PEEL_LAST_STRIP && EPS != 1) {
 #pragma unroll 1
-        for (int s = 0; s + 1 < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
-        sweep(g.T - 1, std::integral_constant<int, EPS>{});
+        for (int s = 0; s + 1 < Tp; s++) sweep(s, std::integral_constant<int, EPS>{});
+        sweep(Tp - 1, std::integral_constant<int, EPS>{});
     } else {
 #pragma unroll 1
-        for (int s = 0; s < g.T; s++) sweep(s, std::integral_constant<int, EPS>{});
+        for (int s = 0; s < Tp; s++) sweep(s, std::integral_constant<int, EPS>{});
     }
+    unsigned *const eps_ph = PERSIST ? eps_out + (size_t)ph * eps_stride : eps_out; // PERSIST: one row of words per phase
     if (EPS == 1) {
         __syncthreads();
         if (w == 0) {
-            float x = lane < NW ? eps_lds[((g.T - 1) & 1) * 16 + lane] : 0.f;
+            float x = lane < NW ? eps_lds[((Tp - 1) & 1) * 16 + lane] : 0.f;
             x = wave_max_nonneg(x);
-            if (lane == 0) eps_out[(size_t)(g.T - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
+            if (lane == 0) eps_out[(size_t)(Tp - 1) * eps_stride + blockIdx.x] = __float_as_uint(x);
         }
     }
     if (EPS == 2 || EPS == 3) {
-        const int witnessed = EPS == 3 ? g.T - 1 : g.T; // sweeps that ran in witness mode
+        const int witnessed = EPS == 3 ? Tp - 1 : Tp; // sweeps that ran in witness mode
         // sweeps this wavefront vouches for; taking turns they add up to the launch, otherwise one wavefront must have all
         if (lane == 0) eps_lds[w] = (float)seen_n;
         __syncthreads();
         if (w == 0) {
             const float x = lane < NW ? eps_lds[lane] : 0.f;
             const float n = wit_rot ? wave_sum16(x) : wave_max_nonneg(x);
-            if (lane == 0) eps_out[blockIdx.x] = __float_as_uint(n == (float)witnessed ? __builtin_inff() : 0.f);
+            if (lane == 0) eps_ph[blockIdx.x] = __float_as_uint(n == (float)witnessed ? __builtin_inff() : 0.f);
             if (EPS == 3) { // second word: Eps of the last sweep, exact
                 const float x = wave_max_nonneg(lane < NW ? eps_lds[16 + lane] : 0.f);
                 if (lane == 0) eps_out[(size_t)eps_stride + blockIdx.x] = __float_as_uint(x);
             }
         }
     }
+    if (stamps) st2 = __builtin_amdgcn_s_memtime();
+
+    if constexpr (!PERSIST) {
+        if (lanecore) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((rowcore >> r) & 1u) {
+                    const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
+                    // (non-temporal and agent-scope write-through stores were tried here: both slower)
+                    const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
+                    // P = (p0, p3), Q = (p1, p2)
+                    *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
+                    *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
+                }
+            }
+        }
+        break;
+    } else {
+        if (stamps) { pt_sweep += st2 - pt0; pt0 = st2; }
+        // --- publish: the core rows go back to scale 1 in their registers (exact) and out with write-through stores
+        const __amdgpu_buffer_rsrc_t pu = plane_rsrc(pa.ub[ph & 1]), pv = plane_rsrc(pa.vb[ph & 1]);
+        const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * Tp) : 1.0f;
+        // The lane's column and where it reads its halo from are worked out afresh in every phase, from a copy of the
+        // lane number the optimiser cannot see through: hoisted out of the phase loop they would be two more registers
+        // alive across the sweep loop, which has none to spare (the sweep then reloads spilled coefficients).
+        int lane_x = lane;
+        asm volatile("" : "+v"(lane_x));
+        const int x0x = bx * g.CW - g.HX + 4 * lane_x;
+        int xgx = x0x;
+        bool xrevx = false;
+        if (xedge && !((x0x >= 0) && (x0x + 3 < g.W))) { // (host: W % 4 == 0 and W >= 256, so no group straddles the border)
+            xgx = x0x < 0 ? -x0x - 4 : 2 * g.W - x0x - 4;
+            xrevx = true;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((rowcore >> r) & 1u) { // wave-uniform
+                uP[r] *= fin; uQ[r] *= fin; vP[r] *= fin; vQ[r] *= fin;
+                if (lanecore) {
+                    const unsigned row = 4u * (unsigned)(base + (long long)(y0 + img_row(r)) * g.P); // wave-uniform
+                    store_f4_sc1(pu, row, 4u * (unsigned)x0x, f4{uP[r].x, uQ[r].x, uQ[r].y, uP[r].y});
+                    store_f4_sc1(pv, row, 4u * (unsigned)x0x, f4{vP[r].x, vQ[r].x, vQ[r].y, vP[r].y});
+                }
+            }
+        }
+        if (ph == pa.n_phase - 1) break; // the launch's end publishes the last phase
+        // the constant term back to the scale a phase starts with: a row was swept max(0, Tp - rdist) times
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int nact = Tp - rdist[r] > 0 ? Tp - rdist[r] : 0;
+            const float back = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * nact) : 1.0f;
+            cf[r].gaP *= back; cf[r].gaQ *= back;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's stores have been written through
+        __syncthreads();                                  // ... and so have every other wavefront's
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt_pub += t - pt0; pt0 = t; }
+        int *const dead_lds = (int *)(eps_lds + 31);
+        if (w == 0) {
+            const unsigned target = flag_base + (unsigned)ph + 1u; // "phase ph of this tile is published"
+            if (lane == 0) __hip_atomic_store(pa.flags + tile, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // lanes 0..7 watch the 8 neighbouring tiles (same pair), lane 8 the abort word
+            int nb = -1;
+            if (lane < 8) {
+                const int k = lane < 4 ? lane : lane + 1; // 0..8 without the centre
+                const int nx = bx + k % 3 - 1, ny = by + k / 3 - 1;
+                if (nx >= 0 && nx < g.tiles_x && ny >= 0 && ny < g.tiles_y) nb = pair * tpp + ny * g.tiles_x + nx;
+            } else if (lane == 8) nb = (int)gridDim.x;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int dead = 0;
+            for (;;) {
+                unsigned v = target;
+                if (nb >= 0) v = load_u32_sc1(pa.flags + nb);
+                const bool aborted = lane == 8 && v != 0u;
+                const bool behind = lane < 8 && (int)(v - target) < 0;
+                if (__builtin_amdgcn_ballot_w64(aborted) != 0) { dead = 1; break; }
+                if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)pa.wait_ticks) { // a neighbour never came
+                    dead = 1;
+                    if (lane == 0) {
+                        __hip_atomic_store(pa.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pa.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (lane == 0) *dead_lds = dead;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*dead_lds)) return; // workgroup-uniform (and said so: a divergent exit would put the loop's counters into VGPRs)
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt_wait += t - pt0; pt0 = t; }
+        // --- reload the halo: whole rows outside the core rows, the side lanes of core rows (host: W % 4 == 0 and
+        // the image at least as large as the region, so every group is an aligned group, read backwards where mirrored)
+        {
+            f4 tu[R], tv[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned row = 4u * (unsigned)(base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P); // wave-uniform
+                tu[r] = f4{uP[r].x, uQ[r].x, uQ[r].y, uP[r].y};
+                tv[r] = f4{vP[r].x, vQ[r].x, vQ[r].y, vP[r].y};
+                if (!((rowcore >> r) & 1u) || !lanecore) {
+                    tu[r] = load_f4_sc1(pu, row, 4u * (unsigned)xgx);
+                    tv[r] = load_f4_sc1(pv, row, 4u * (unsigned)xgx);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (xrevx) { // (mirrored groups lie outside the image: never core lanes)
+                    tu[r] = f4{tu[r].w, tu[r].z, tu[r].y, tu[r].x};
+                    tv[r] = f4{tv[r].w, tv[r].z, tv[r].y, tv[r].x};
+                }
+                uP[r] = f2{tu[r].x, tu[r].w}; uQ[r] = f2{tu[r].y, tu[r].z};
+                vP[r] = f2{tv[r].x, tv[r].w}; vQ[r] = f2{tv[r].y, tv[r].z};
+            }
+        }
+        ph++;
+    }
+    } // phases
 #undef HS_ROW
 #undef HS_ACT
 #undef HS_CROSS
 #undef HS_PUBLISH
-    if (stamps) st2 = __builtin_amdgcn_s_memtime();
-
-    if (lanecore) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if ((rowcore >> r) & 1u) {
-                const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
-                // (non-temporal and agent-scope write-through stores were tried here: both slower)
-                const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
-                // P = (p0, p3), Q = (p1, p2)
-                *(float4 *)(u_out + off) = make_float4(uP[r].x * fin, uQ[r].x * fin, uQ[r].y * fin, uP[r].y * fin);
-                *(float4 *)(v_out + off) = make_float4(vP[r].x * fin, vQ[r].x * fin, vQ[r].y * fin, vP[r].y * fin);
-            }
-        }
-    }
     if (stamps && threadIdx.x == 0) {
         __builtin_amdgcn_s_waitcnt(0); // stores issued and acknowledged
         unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
@@ -650,6 +824,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime();
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); // XCC_ID
         o[7] = (unsigned long long)tile;
+        if (PERSIST && gridDim.x <= 8192) { // totals over the phases: sweeps, publish, wait, reload (cycles)
+            unsigned long long *q = stamps + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 32;
+            q[0] = pt_sweep; q[1] = pt_pub; q[2] = pt_wait; q[3] = pt_load; q[4] = pt_first - st1; q[5] = o[3] - st2;
+        }
     }
 }
 
@@ -685,6 +863,23 @@ __global__ __launch_bounds__(NTMAX) void k_jacobi_strip_deriv(const uint8_t *__r
 {
     strip_body<R, NTMAX, EPS, E0, true>(nullptr, u_in, v_in, u_out, v_out, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
                                     fA, fB, coef_w);
+}
+
+// One launch for the whole solve (PersistArgs above).  DERIV: phase 0 computes the derivative words from the frames and
+// leaves the packed plane behind (coef_rw is written); otherwise coef_rw is only read.
+template <int R, int NTMAX, int EPS, int E0, bool DERIV>
+__global__ __launch_bounds__(NTMAX) void k_jacobi_strip_persist(const uint8_t *__restrict__ fA,
+                                                                const uint8_t *__restrict__ fB,
+                                                                uint32_t *coef_rw,
+                                                                const float *__restrict__ u_in,
+                                                                const float *__restrict__ v_in, const StripGeom g,
+                                                                const float ilambda,
+                                                                unsigned *__restrict__ eps_out, const int eps_stride,
+                                                                unsigned long long *__restrict__ stamps,
+                                                                const float eps_thr, const PersistArgs pa)
+{
+    strip_body<R, NTMAX, EPS, E0, DERIV, true>(coef_rw, u_in, v_in, nullptr, nullptr, g, ilambda, eps_out, eps_stride, stamps, eps_thr,
+                                               fA, fB, coef_rw, pa);
 }
 
 // ------------------------------------------------------------------------------------------

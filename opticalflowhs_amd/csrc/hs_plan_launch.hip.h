@@ -470,6 +470,62 @@ hipError_t launch_strip_deriv_e(const hsflow_ctx *c, const StripPlan &p, const f
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The strip kernel as ONE persistent launch per solve (k_jacobi_strip_persist, hs_kernels_strip.hip.h).
+// ------------------------------------------------------------------------------------------
+constexpr unsigned kPersistWaitTicks = 5000000u; // 50 ms of the 100 MHz clock: a healthy wait is a few microseconds
+
+// Why this solve cannot run as one persistent launch (nullptr: it can).  sp: the strip plan for T sweeps per phase.
+const char *persist_obstacle(const hsflow_ctx *c, const StripPlan &sp, int iters, const hsflow_params &p, bool async, bool use_eps)
+{
+    static const bool off = getenv("HSFLOW_NO_PERSIST") != nullptr;
+    const hsk::StripGeom &g = sp.g;
+    if (off) return "HSFLOW_NO_PERSIST is set";
+    if (c->persist_off) return "a persistent launch timed out on this context earlier";
+    if (sp.fold) return "the folded kernel has no persistent form";
+    if (sp.R != 5 || g.NW * 64 > 1024) return "the persistent form is compiled for 5 rows per lane";
+    if (iters <= g.T) return "a single phase";
+    if ((g.W & 3) != 0 || g.W < 256 || g.H < g.NW * sp.R) return "the frame must be at least one region large and its width a multiple of 4";
+    if (g.CH < g.T || g.CW < g.HX) return "the halo reaches past the neighbouring tiles";
+    if (sp.tiles > (c->num_cu > 0 ? c->num_cu : kNumCU) || sp.tiles > kMaxPersistTiles) return "more tiles than compute units: not all workgroups would be resident";
+    if (use_eps && !async) return "synchronous ITER|EPS measures its last sweep: launch per fuse_steps";
+    if (c->device >= 0 && g_live_ctx[c->device & 63].load() > 1) return "another context is alive on this device";
+    return nullptr;
+}
+
+template <int R, int NTMAX, int EPS, bool DERIV, int E0>
+hipError_t launch_persist_te(hsflow_ctx *c, const StripPlan &p, const hsk::PersistArgs &pa, const float *ui, const float *vi,
+                             float coeff, bool configure_only)
+{
+    auto kern = hsk::k_jacobi_strip_persist<R, NTMAX, EPS, E0, DERIV>;
+    static std::atomic<int> resident[64]; // workgroups per CU the runtime promises for this shape (0: not asked yet)
+    const int dv = c->device & 63;
+    if (resident[dv].load() == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), p.g.NW * 64, (size_t)p.lds_bytes);
+        if (e != hipSuccess) return e;
+        resident[dv] = nb >= 1 ? nb : -1;
+    }
+    if (resident[dv].load() < 1) return hipErrorCooperativeLaunchTooLarge;
+    if (configure_only) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi, p.g, coeff,
+                       c->epsPtr, c->epsStride, p.tiles <= 8192 ? c->dStamps : nullptr, c->epsThr, pa);
+    return hipGetLastError();
+}
+
+// eps: 0 plain phases, 2 witness phases (one row of c->epsStride words per phase at c->epsPtr)
+hipError_t launch_persist(hsflow_ctx *c, const StripPlan &sp, const hsk::PersistArgs &pa, int eps, bool deriv, const float *ui,
+                          const float *vi, float coeff, bool cfg = false)
+{
+    if (sp.R != 5) return hipErrorInvalidConfiguration;
+    if (eps == 2) return deriv ? launch_persist_te<5, 1024, 2, true, 0>(c, sp, pa, ui, vi, coeff, cfg)
+                               : launch_persist_te<5, 1024, 2, false, 0>(c, sp, pa, ui, vi, coeff, cfg);
+    return deriv ? launch_persist_te<5, 1024, 0, true, 0>(c, sp, pa, ui, vi, coeff, cfg)
+                 : launch_persist_te<5, 1024, 0, false, 0>(c, sp, pa, ui, vi, coeff, cfg);
+}
+
 // Can the first launch of a solve compute the derivatives itself (k_jacobi_strip_deriv / k_jacobi_fold_deriv)?
 // The kernels' reflection argument wants a single bounce: an image at least as large as one workgroup's
 // region (256 or 128 columns x all its rows).

@@ -74,9 +74,77 @@ struct Profiler { // brackets kernels with events when params.profile is set
     }
 };
 
+// --- the persistent launch (HSFLOW_KERNEL_PERSIST) -------------------------------------------------------------
+// Buffers it needs (allocation only: called outside any capture).
+int persist_reserve(hsflow_ctx *c)
+{
+    const size_t px = (size_t)c->plane * c->N;
+    if (!c->dUp) HS_HIP(c, hipMalloc((void **)&c->dUp, px * sizeof(float)));
+    if (!c->dVp) HS_HIP(c, hipMalloc((void **)&c->dVp, px * sizeof(float)));
+    if (!c->dFlags) {
+        HS_HIP(c, hipMalloc((void **)&c->dFlags, (size_t)(kMaxPersistTiles + 1) * sizeof(unsigned)));
+        c->persist_tiles = 0;
+    }
+    if (!c->hErr) {
+        HS_HIP(c, hipHostMalloc((void **)&c->hErr, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HS_HIP(c, hipHostGetDevicePointer((void **)&c->hErrDev, c->hErr, 0));
+        *c->hErr = 0u;
+    }
+    return HSFLOW_OK;
+}
+
+// The tiles' phase counters count up across solves and agree at every launch boundary as long as the grid stays the
+// same; a different grid (or an aborted launch) starts from cleared counters.  Enqueued ahead of the launch, outside
+// any capture.
+int persist_prepare_flags(hsflow_ctx *c, int tiles)
+{
+    if (c->persist_tiles == tiles) return HSFLOW_OK;
+    HS_HIP(c, hipMemsetAsync(c->dFlags, 0, (size_t)(kMaxPersistTiles + 1) * sizeof(unsigned), c->stream));
+    c->persist_tiles = tiles;
+    return HSFLOW_OK;
+}
+
+// A persistent launch gave up waiting (another grid held part of the CUs, a neighbour never came): the flow it left is
+// invalid.  The context goes back to a launch per fuse_steps iterations for good.
+void persist_failed(hsflow_ctx *c)
+{
+    if (c->hErr) *c->hErr = 0u;
+    c->persist_tiles = 0;
+    c->persist_off = true;
+    c->persist_unchecked = false;
+}
+
+// Did the last persistent launch(es) of this context give up?  Only meaningful once the stream has drained.
+bool persist_error(const hsflow_ctx *c) { return c->hErr && *(volatile unsigned *)c->hErr != 0u; }
+
+// One persistent launch = `iters` sweeps in phases of sp.g.T: input dU[cur] (or zero), output dU[cur ^ 1]; the phases
+// alternate between that buffer and the third one so that the last phase lands in it.
+int enqueue_persist(hsflow_ctx *c, const StripPlan &sp0, int iters, int eps, bool deriv, int zero_in, float coeff)
+{
+    StripPlan sp = sp0;
+    sp.g.zero_in = zero_in;
+    hsk::PersistArgs pa;
+    const int T = sp.g.T;
+    pa.n_phase = (iters + T - 1) / T;
+    pa.T_last = iters - (pa.n_phase - 1) * T;
+    pa.flags = c->dFlags;
+    pa.err = c->hErrDev;
+    // (HSFLOW_PERSIST_WAIT_TICKS: test hook -- with 0 every wait that is not already satisfied gives up, which drives the
+    // abort and fall-back path)
+    static const char *ticks_env = getenv("HSFLOW_PERSIST_WAIT_TICKS");
+    pa.wait_ticks = ticks_env ? (unsigned)strtoul(ticks_env, nullptr, 10) : kPersistWaitTicks;
+    const int a = c->cur, b = a ^ 1;
+    const int lastb = (pa.n_phase - 1) & 1;
+    pa.ub[lastb] = c->dU[b]; pa.vb[lastb] = c->dV[b];
+    pa.ub[lastb ^ 1] = c->dUp; pa.vb[lastb ^ 1] = c->dVp;
+    HS_HIP(c, launch_persist(c, sp, pa, eps, deriv, c->dU[a], c->dV[a], coeff));
+    c->cur = b;
+    return HSFLOW_OK;
+}
+
 // Enqueue derivative pass + `iters` Jacobi sweeps (no host synchronisation inside).
 int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters, int kernel, int T,
-                  const JPlan *plan, const JPlan *tail_plan, Profiler &prof, bool do_deriv, bool zero_flow)
+                  const JPlan *plan, const JPlan *tail_plan, Profiler &prof, bool do_deriv, bool zero_flow, bool persist = false)
 {
     // u = v = 0 at the start (reference behaviour, use_previous = 0): instead of clearing two
     // planes and reading them back, the first launch is told that its input is zero.
@@ -92,6 +160,14 @@ int enqueue_fixed(hsflow_ctx *c, const hsflow_params &p, float coeff, int iters,
         prof.end();
     }
     int left = iters, launches = 0;
+    if (persist) { // the whole budget as one launch
+        prof.begin(1);
+        const int st = enqueue_persist(c, plan->s, iters, 0, fuse, zero_in, coeff);
+        prof.end();
+        if (st) return st;
+        left = 0;
+        launches = 1;
+    }
     while (left > 0) {
         const int a = c->cur, b = a ^ 1;
         if (kernel == HSFLOW_KERNEL_SIMPLE) {
@@ -211,6 +287,15 @@ void dump_stamps(hsflow_ctx *c, int tiles)
         const unsigned long long *o = &h[(size_t)i * 8];
         fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, o[1] - o[0], o[2] - o[1], o[3] - o[2], o[3] - o[0],
                 o[5] - o[4], o[6], o[7]);
+    }
+    // the persistent launch: cycles spent in sweeps / publish (stores drained, barrier) / wait (counters) / halo reload,
+    // summed over the phases, per workgroup
+    if (c->info.persistent && tiles <= 8192) {
+        std::vector<unsigned long long> pq((size_t)tiles * 32);
+        if (hipMemcpy(pq.data(), c->dStamps + (size_t)tiles * 8, pq.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < tiles; i++)
+                fprintf(f, "P %d %llu %llu %llu %llu %d %llu %llu\n", i, pq[(size_t)i * 32], pq[(size_t)i * 32 + 1], pq[(size_t)i * 32 + 2],
+                        pq[(size_t)i * 32 + 3], c->info.persistent, pq[(size_t)i * 32 + 4], pq[(size_t)i * 32 + 5]);
     }
     // per-sweep end stamps of the strip kernel (cycles since the end of the load phase), HSFLOW_DEBUG_STAMPS_SWEEPS=1
     if (getenv("HSFLOW_DEBUG_STAMPS_SWEEPS") && tiles <= 8192 && c->info.kernel == HSFLOW_KERNEL_STRIP) {

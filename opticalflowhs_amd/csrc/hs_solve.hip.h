@@ -7,6 +7,19 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async);
 
 // Settles an ITER|EPS solve that hsflow_solve_async left unverified: waits for the stream, looks at the
 // witness words and, if they do not prove "no early stop", runs the exact pass from the saved start.
+// After the stream has drained: did an asynchronous persistent launch give up?  Its flow is invalid then; the context
+// goes back to a launch per fuse_steps iterations and the caller is told.
+int check_persist(hsflow_ctx *c)
+{
+    if (!c->persist_unchecked) return HSFLOW_OK;
+    c->persist_unchecked = false;
+    if (!persist_error(c)) return HSFLOW_OK;
+    persist_failed(c);
+    c->coef_valid = false;
+    return fail(c, HSFLOW_E_DEVICE, "a persistent launch of an asynchronous solve timed out (another grid on the device?): its flow is invalid; "
+                                    "this context now launches per fuse_steps iterations, solve again");
+}
+
 int settle_pending(hsflow_ctx *c)
 {
     if (!c->pend.active) return HSFLOW_OK;
@@ -20,14 +33,21 @@ int settle_pending(hsflow_ctx *c)
     if (st0) return st0;
     HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
-    if (witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last, false)) {
+    const bool gave_up = c->persist_unchecked && persist_error(c); // a persistent launch that timed out proves nothing
+    c->persist_unchecked = false;
+    if (gave_up) {
+        persist_failed(c);
+        c->coef_valid = false;
+    }
+    if (!gave_up && witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last, false)) {
         c->info.iterations_done = c->pend.iters;
         c->info.last_eps = NAN; // not measured by an asynchronous solve; hsflow_get_info measures it on demand (c->lastl)
         return HSFLOW_OK;
     }
     c->lastl.valid = false;
     hsflow_params q = c->pend.params;
-    q.reuse_derivatives = 1; // the coefficient plane of that solve is still in place
+    q.reuse_derivatives = gave_up ? 0 : 1; // the coefficient plane of that solve is still in place
+    if (q.kernel == HSFLOW_KERNEL_PERSIST) q.kernel = HSFLOW_KERNEL_STRIP;
     if (q.use_previous) {
         const size_t px = (size_t)c->plane * c->N;
         c->cur = c->pend.cur0;
@@ -57,7 +77,8 @@ int measure_last_eps(hsflow_ctx *c)
     c->epsPtr = c->dEpsTiles;
     c->epsStride = stride;
     c->epsThr = L.eps_thr;
-    const hipError_t e = launch_j(c, L.plan, 3, c->dU[a], c->dV[a], c->dU[b], c->dV[b], L.coeff, false, L.zero_in, false);
+    const float *ui = L.from_third ? c->dUp : c->dU[a], *vi = L.from_third ? c->dVp : c->dV[a];
+    const hipError_t e = launch_j(c, L.plan, 3, ui, vi, c->dU[b], c->dV[b], L.coeff, false, L.zero_in, false);
     HS_HIP(c, e);
     if ((st = eps_collect_enqueue(c, 2, 0, 0, stride))) return st; // (resets epsPtr / epsStride)
     HS_HIP(c, hipStreamSynchronize(c->stream));
@@ -277,6 +298,7 @@ struct SolveSetup {
     long long budget;   // sweep budget (huge when ITER does not apply)
     int T;              // sweeps per full launch
     JPlan plan;         // launch plan for T sweeps
+    bool persist;       // the whole budget as ONE persistent launch in phases of T sweeps (HSFLOW_KERNEL_PERSIST)
     hsflow_params eff;  // the caller's parameters as the solve paths use them (strip_rows may have been fixed, see prepare_solve)
 };
 
@@ -291,16 +313,25 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
     const long long budget = S.budget;
     JPlan tail;
     const int iters = (int)budget;
-    const int rem = multi ? iters % T : 0;
+    const bool persist = S.persist;
+    const int rem = (multi && !persist) ? iters % T : 0;
     if (rem && !make_jplan(c, kernel, rem, p, tail))
         return fail(c, HSFLOW_E_SIZE, "no feasible launch plan for the tail launch");
     const bool zero = !p.use_previous;
     const bool do_deriv = !(p.reuse_derivatives && c->coef_valid && c->coef_mode == HSFLOW_MODE_CV);
     c->info.deriv_fused = do_deriv && !p.profile && multi && strip_deriv_fusable(c, iters >= T ? plan : tail); // enqueue_fixed's rule
+    if (persist) { // buffers and phase counters: outside any capture
+        if ((st = persist_reserve(c)) || (st = persist_prepare_flags(c, plan.s.tiles))) return st;
+    }
     if (p.use_graph && !p.profile) {
-        GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+        GraphKey key{p.mode, persist ? HSFLOW_KERNEL_PERSIST : kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                      c->info.groups_per_thread, zero ? 0 : c->cur, p.use_previous * 2 + (do_deriv ? 1 : 0), coeff};
         auto configure = [&]() -> int {
+            if (persist) {
+                hsk::PersistArgs none{};
+                HS_HIP(c, launch_persist(c, plan.s, none, 0, c->info.deriv_fused != 0, nullptr, nullptr, coeff, true));
+                return HSFLOW_OK;
+            }
             if (multi) {
                 HS_HIP(c, launch_j(c, plan, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (rem) HS_HIP(c, launch_j(c, tail, false, nullptr, nullptr, nullptr, nullptr, coeff, true));
@@ -311,7 +342,7 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
             return HSFLOW_OK;
         };
         auto enqueue = [&](int *n) -> int {
-            const int e = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
+            const int e = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero, persist);
             *n = c->info.jacobi_launches;
             return e;
         };
@@ -319,14 +350,28 @@ int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Prof
         if ((st = run_captured(c, key, configure, enqueue, &n))) return st;
         c->info.jacobi_launches = n;
     } else {
-        st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero);
+        if (persist) {
+            hsk::PersistArgs none{};
+            HS_HIP(c, launch_persist(c, plan.s, none, 0, c->info.deriv_fused != 0, nullptr, nullptr, coeff, true));
+        }
+        st = enqueue_fixed(c, p, coeff, iters, kernel, T, &plan, &tail, prof, do_deriv, zero, persist);
         if (st) return st;
     }
     c->coef_valid = true;
     c->coef_mode = HSFLOW_MODE_CV;
     c->info.iterations_done = iters;
+    if (persist && async) c->persist_unchecked = true; // looked at when the stream is next drained (check_persist)
     if (!async) {
         HS_HIP(c, hipStreamSynchronize(c->stream));
+        if (persist && persist_error(c)) { // a wait timed out: back to a launch per fuse_steps iterations, for good
+            persist_failed(c);
+            c->cur ^= 1;            // the starting flow is intact (the phases wrote the other two buffers)
+            c->coef_valid = false;  // a workgroup that never started left its part of the derivative plane unwritten
+            hsflow_params q = p;
+            if (q.kernel == HSFLOW_KERNEL_PERSIST) q.kernel = HSFLOW_KERNEL_STRIP;
+            q.reuse_derivatives = 0;
+            return solve_impl(c, &q, false);
+        }
         prof.collect();
         if (c->dStamps && (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD)) dump_stamps(c, plan.s.tiles);
     }
@@ -373,7 +418,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         }
         stride = std::max(stride, plan_eps_stride(kernel, tailp));
         // (a tail of one sweep is measured, not witnessed: the synchronous pass's mode 3; an asynchronous pass needs it able)
-        if (witness && (async || iters % T > 1) && !strip_has_witness(tailp)) witness = false;
+        if (witness && !S.persist && (async || iters % T > 1) && !strip_has_witness(tailp)) witness = false; // (persist: the tail phase keeps the plan's geometry)
     }
     if (async && !witness)
         return fail(c, HSFLOW_E_ARG, "solve_async with ITER|EPS: this launch plan (core tile thinner than a strip) cannot run witness launches; "
@@ -391,8 +436,10 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
         c->epsThr = p.epsilon > 0 ? (float)p.epsilon : 0.f;
         if ((double)c->epsThr < p.epsilon) c->epsThr = std::nextafterf(c->epsThr, INFINITY);
         if (c->epsThr < FLT_MIN) c->epsThr = c->epsThr > 0.f ? FLT_MIN : 0.f; // the kernels scale it through its exponent bits
-        const int n_launch = (iters + T - 1) / T;
+        const bool persist = S.persist && async; // (prepare_solve grants it to asynchronous solves only)
+        const int n_launch = (iters + T - 1) / T; // persist: phases of the one launch; the witness words are laid out alike
         const int last_chunk = iters - (n_launch - 1) * T;
+        if (persist && ((st = persist_reserve(c)) || (st = persist_prepare_flags(c, plan.s.tiles)))) return st;
         // Synchronous solves report last_eps at once: their last launch measures its final sweep (mode 3: two words
         // per workgroup, the witness and that sweep's Eps).  Asynchronous solves run witness launches only; their
         // last_eps is measured if and when hsflow_get_info asks for it (measure_last_eps).
@@ -417,7 +464,18 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             }
             int zero_w = p.use_previous ? 0 : 1;
             if (zero_w) c->cur = 0;
-            for (int L = 0; L < n_launch; L++) {
+            if (persist) { // one launch, a row of witness words per phase
+                c->epsPtr = c->dEpsTiles;
+                prof.begin(1);
+                const int e = enqueue_persist(c, plan.s, iters, 2, fuse, zero_w, coeff);
+                prof.end();
+                if (e) return e;
+                // what measure_last_eps needs: the last phase again as an ordinary launch, from the third buffer
+                c->lastl.plan = last_chunk != T ? tailp : plan; c->lastl.zero_in = 0; c->lastl.coeff = coeff; c->lastl.eps_thr = c->epsThr;
+                c->lastl.from_third = true;
+                launches = 1;
+            }
+            for (int L = persist ? n_launch : 0; L < n_launch; L++) {
                 const bool is_last = L == n_launch - 1;
                 const JPlan &cp = (is_last && last_chunk != T) ? tailp : plan;
                 const int a = c->cur, b = a ^ 1;
@@ -428,6 +486,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 HS_HIP(c, e);
                 if (is_last && async) { // what measure_last_eps needs
                     c->lastl.plan = cp; c->lastl.zero_in = zero_w; c->lastl.coeff = coeff; c->lastl.eps_thr = c->epsThr;
+                    c->lastl.from_third = false;
                 }
                 c->cur = b;
                 zero_w = 0;
@@ -443,9 +502,15 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                                        plan_eps_stride(kernel, last_chunk != T ? tailp : plan));
         };
         if (p.use_graph && !p.profile) {
-            GraphKey key{p.mode, kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
+            GraphKey key{p.mode, persist ? HSFLOW_KERNEL_PERSIST : kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
                          c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0) + (async ? 4 : 0), coeff, c->epsThr};
             auto configure = [&]() -> int {
+                if (persist) {
+                    hsk::PersistArgs none{};
+                    HS_HIP(c, launch_persist(c, plan.s, none, 2, fuse_deriv, nullptr, nullptr, coeff, true));
+                    HS_HIP(c, launch_j(c, has_tail ? tailp : plan, 3, nullptr, nullptr, nullptr, nullptr, coeff, true)); // measure_last_eps
+                    return HSFLOW_OK;
+                }
                 HS_HIP(c, launch_j(c, plan, 2, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 HS_HIP(c, launch_j(c, plan, last_mode, nullptr, nullptr, nullptr, nullptr, coeff, true));
                 if (has_tail) HS_HIP(c, launch_j(c, tailp, last_mode, nullptr, nullptr, nullptr, nullptr, coeff, true));
@@ -471,19 +536,25 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 c->lastl.zero_in = (n_launch == 1 && !p.use_previous) ? 1 : 0;
                 c->lastl.coeff = coeff;
                 c->lastl.eps_thr = c->epsThr;
+                c->lastl.from_third = persist;
             }
-        } else if ((st = enqueue())) {
-            return st;
+        } else {
+            if (persist) {
+                hsk::PersistArgs none{};
+                HS_HIP(c, launch_persist(c, plan.s, none, 2, fuse_deriv, nullptr, nullptr, coeff, true));
+            }
+            if ((st = enqueue())) return st;
         }
         c->coef_valid = true;
         c->coef_mode = HSFLOW_MODE_CV;
+        if (persist) c->persist_unchecked = true;
         if (async) { // the check is owed: hsflow_synchronize (or the next call that needs results) settles it
             c->lastl.valid = true;
             c->pend.active = true;
             c->pend.params = p;
             c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
             c->pend.stride = stride; c->pend.n_first = n_launch - 1; c->pend.cnt_first = plan_eps_stride(kernel, plan);
-            c->pend.cnt_last = plan_eps_stride(kernel, last_chunk != T ? tailp : plan);
+            c->pend.cnt_last = plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan);
             c->info.iterations_done = iters;
             c->info.jacobi_launches = launches;
             return HSFLOW_OK;
@@ -689,7 +760,10 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     // twice the tiles across, so small frames reach more CUs -- measured 5-25 % faster from 160x120 to
     // 1600x900 at 100 sweeps, tools/crossover.py).
     const bool small_frame = (long long)c->W * c->H * c->N <= 1500000LL;
-    const int kernel = p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel : (small_frame ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
+    // PERSIST is the strip kernel as one launch per solve; AUTO takes it where it can run (persist_obstacle)
+    const bool persist_asked = p.kernel == HSFLOW_KERNEL_PERSIST;
+    const int kernel = persist_asked ? HSFLOW_KERNEL_STRIP
+                                     : p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel : (small_frame ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
     if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP &&
         kernel != HSFLOW_KERNEL_FOLD)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
@@ -733,7 +807,21 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
         c->info.groups_per_thread = 1; c->info.tiles = 0; c->info.lds_bytes = 0;
     }
     c->info.kernel = kernel;
-    S = SolveSetup{coeff, kernel, multi, use_iter, use_eps, budget, T, plan, eff};
+    bool persist = false;
+    // AUTO keeps the launch per fuse_steps: measured on MI355X at 1080p / 100 the persistent launch spends as long at a
+    // phase boundary (write-through publish 2.6 us + counters 3.2 us + halo reload 4 us) as the stream does at a kernel
+    // boundary -- ITER 0.148 against 0.149 ms, ITER|EPS slower -- so it runs on request only
+    // (HSFLOW_PERSIST_AUTO=1 lets AUTO take it, for experiments).
+    static const bool persist_auto = getenv("HSFLOW_PERSIST_AUTO") != nullptr;
+    if (persist_asked || (persist_auto && p.kernel == HSFLOW_KERNEL_AUTO && kernel == HSFLOW_KERNEL_STRIP)) {
+        const char *why = !(use_iter && p.max_iter > 0 && budget <= (1 << 16)) ? "needs a sweep budget (ITER)"
+                                                                               : persist_obstacle(c, plan.s, (int)budget, p, async, use_eps);
+        if (!why && use_eps && !strip_has_witness(plan)) why = "this launch plan cannot run witness phases";
+        if (!why) persist = true;
+        else if (persist_asked) return fail(c, HSFLOW_E_SIZE, std::string("HSFLOW_KERNEL_PERSIST: ") + why);
+    }
+    c->info.persistent = persist ? (int)((budget + T - 1) / T) : 0;
+    S = SolveSetup{coeff, kernel, multi, use_iter, use_eps, budget, T, plan, persist, eff};
     return HSFLOW_OK;
 }
 

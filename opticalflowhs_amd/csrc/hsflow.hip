@@ -145,6 +145,11 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
     c->epsPtr = c->dEps;
+    {
+        int ncu = 0;
+        HS_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        c->num_cu = ncu;
+    }
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     // deterministic contents for padding columns and the initial flow
     HS_TRY(hipMemsetAsync(c->dA, 0, px, c->stream));
@@ -156,6 +161,8 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     }
     HS_TRY(hipStreamSynchronize(c->stream));
 #undef HS_TRY
+    g_live_ctx[device & 63]++;
+    c->counted = true;
     *out = c;
     return HSFLOW_OK;
 }
@@ -189,6 +196,9 @@ int hsflow_destroy(hsflow_ctx *c)
     for (int i = 0; i < 2; i++) { hipFree(c->dU[i]); hipFree(c->dV[i]); }
     hipFree(c->dEps);
     hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
+    hipFree(c->dUp); hipFree(c->dVp); hipFree(c->dFlags);
+    if (c->hErr) hipHostFree(c->hErr);
+    if (c->counted) g_live_ctx[c->device & 63]--;
     hipFree(c->dStamps);
     hipFree(c->dScratch);
     if (c->hEps) hipHostFree(c->hEps);
@@ -363,7 +373,7 @@ int hsflow_synchronize(hsflow_ctx *c)
     if (st) return st;
     if ((st = settle_pending(c))) return st;
     HS_HIP(c, hipStreamSynchronize(c->stream));
-    return HSFLOW_OK;
+    return check_persist(c);
 }
 
 int hsflow_get_flow(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size_t vs)
@@ -375,6 +385,7 @@ int hsflow_get_flow(hsflow_ctx *c, int pair, float *u, size_t us, float *v, size
     if ((us & 3) || (vs & 3) || us < rowb || vs < rowb) return fail(c, HSFLOW_E_SIZE, "flow stride must be a multiple of 4 and >= 4*width");
     if ((st = settle_pending(c))) return st;
     HS_HIP(c, hipStreamSynchronize(c->stream));
+    if ((st = check_persist(c))) return st;
     HS_HIP(c, hipMemcpy2D(u, us, c->dU[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
     HS_HIP(c, hipMemcpy2D(v, vs, c->dV[c->cur] + pair * c->plane, (size_t)c->P * 4, rowb, c->H, hipMemcpyDeviceToHost));
     return HSFLOW_OK;
@@ -547,7 +558,7 @@ int hsflow_plan_query(int width, int height, int n_pairs, const hsflow_params *p
         st = prepare_solve(&c, p, false, S);
         if (!st) {
             const long long b = S.budget > (1LL << 30) ? 0 : S.budget;
-            c.info.jacobi_launches = S.multi ? (int)((b + S.T - 1) / S.T) : (int)b;
+            c.info.jacobi_launches = S.persist ? 1 : S.multi ? (int)((b + S.T - 1) / S.T) : (int)b;
         }
     } else if (p.mode == HSFLOW_MODE_CLASSIC || p.mode == HSFLOW_MODE_CLASSIC_AS_SHIPPED) {
         ClassicSetup S;

@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (HsflowError, HsflowInfo, HsflowParams, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD,
+from ._lib import (HsflowError, HsflowInfo, HsflowParams, KERNEL_AUTO, KERNEL_FUSED, KERNEL_SIMPLE, KERNEL_STRIP, KERNEL_FOLD, KERNEL_PERSIST,
                    MODE_CLASSIC, MODE_CV, TERM_EPS, TERM_ITER)
 
 TermCriteria = collections.namedtuple("TermCriteria", "type max_iter epsilon")

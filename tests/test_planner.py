@@ -17,7 +17,12 @@ def check_plan(hs, W, H, N, it, info, kw):
     if k == hs.KERNEL_SIMPLE:
         assert T == 1 and info["jacobi_launches"] == it
         return
-    assert 1 <= T <= 32 and info["jacobi_launches"] == ceil_div(it, T)
+    assert 1 <= T <= 32
+    if info["persistent"]:   # the whole budget as one launch in phases of T sweeps (HSFLOW_KERNEL_PERSIST): one tile per CU at most
+        assert k == hs.KERNEL_STRIP and info["jacobi_launches"] == 1 and info["persistent"] == ceil_div(it, T) >= 2
+        assert info["tiles"] <= 256 and W % 4 == 0 and info["tile_h"] >= T
+    else:
+        assert info["jacobi_launches"] == ceil_div(it, T)
     assert info["tile_w"] >= 1 and info["tile_h"] >= 1
     assert info["tiles"] == ceil_div(W, info["tile_w"]) * ceil_div(H, info["tile_h"]) * N      # core tiles cover the frame once
     assert info["threads"] % 64 == 0 and 64 <= info["threads"] <= 1024

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction mix of the sweep loop of the strip / fold kernels, from a device assembly file
-(hipcc -S --cuda-device-only ...).   usage: tools/isa_loop.py file.s [substring of the mangled kernel name ...] [--dump]
+(hipcc -S --cuda-device-only ...).   usage: tools/isa_loop.py file.s [substring of the mangled kernel name ...] [--dump] [--inner]
 The sweep loop = the strongly connected component of the kernel's control-flow graph that holds the most
 v_pk_fma_f32 (every block counted once, i.e. all rows active).  The issue estimate prices packed and DPP
 instructions at 4.2 cycles and the other VALU instructions at 2.3 (profiles/r01_ubench_valu.txt)."""
@@ -126,6 +126,20 @@ def main():
                 best, bestn = comp, n
         if not best:
             continue
+        if '--inner' in sys.argv:
+            # persistent kernels: the phase loop contains the sweep loop.  Drop the blocks of the exchange (global
+            # stores / loads, s_sleep) and take the component with the most packed multiply-adds of what is left.
+            keep = [b for b in best if not any(x.startswith(('global_store', 'global_load', 'buffer_store', 'buffer_load', 's_sleep')) for x in ins[b])]
+            sub = {b: [w for w in succ.get(b, []) if w in set(keep)] for b in keep}
+            best2, bestn2 = None, 0
+            for comp in sccs(keep, sub):
+                if len(comp) == 1 and comp[0] not in sub.get(comp[0], []):
+                    continue
+                n = sum(1 for b in comp for x in ins[b] if x.startswith('v_pk_fma'))
+                if n > bestn2:
+                    best2, bestn2 = comp, n
+            if best2:
+                best = best2
         order = [n for n, _ in bl if n in set(best)]
         body = [x for n in order for x in ins[n]]
         c = classify(body)
