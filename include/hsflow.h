@@ -216,6 +216,12 @@ int hsflow_get_flow_async(hsflow_ctx *ctx, int pair, float *u, size_t u_stride, 
  * the row-slab halo exchange).  set_ writes into the flow the next
  * use_previous=1 solve continues from.  Both settle an ITER|EPS check that hsflow_solve_async still
  * owes (they wait for the stream in that case); after an ITER-only solve they only enqueue. */
+/* Where the context holds the current flow of `pair`, without a copy: device pointers to row 0 and the row
+ * stride in bytes (rows are `width` floats; the pitch is that of hsflow_info).  Settles an ITER|EPS check that
+ * hsflow_solve_async still owes and waits for the stream, so the planes are final; they stay valid and unchanged
+ * until the next call that changes this context's flow (solve, set_flow_device).  What a consumer on the device
+ * (rendering, the next stage of a pipeline) reads instead of HSOpticalFlowOpenCL.cpp:655-675's blocking read-back. */
+int hsflow_flow_view_device(hsflow_ctx *ctx, int pair, const float **d_u, const float **d_v, size_t *stride_bytes);
 int hsflow_get_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, void *d_u,
                            size_t u_stride, void *d_v, size_t v_stride);
 int hsflow_set_flow_device(hsflow_ctx *ctx, int pair, int row0, int nrows, const void *d_u,
@@ -277,6 +283,20 @@ int hsflow_pipeline_submit(hsflow_pipeline *pl, const uint8_t *prev, size_t prev
 int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *prev, size_t prev_stride,
                               const uint8_t *curr, size_t curr_stride, float *u, size_t u_stride,
                               float *v, size_t v_stride, const hsflow_params *params, uint64_t *ticket);
+/* The same for a stream of pairs that are ALREADY IN DEVICE MEMORY (a decoder's or a camera's output, the frames of a
+ * resident sequence): the frames are copied device to device into the slot, the flow stays in the slot and is handed
+ * out by hsflow_pipeline_flow_device -- no host buffer anywhere.  This is the reference's camera loop
+ * (OpticalFlowOpenCV.cpp:91-95: fresh frames, ITER|EPS, every pair) at the speed of the solver: while pair k's
+ * early-stop check is still owed, pair k+1 is already running on the next slot's stream; the check is looked at when
+ * somebody asks for pair k (wait / flow_device / info / the slot's reuse `depth` submissions later), and a pair whose
+ * early stop fired is re-solved from its slot's frames, which nothing has touched.  The caller's frame buffers must
+ * be complete when submit is called (they are read by a copy enqueued on the slot's stream) and may be reused once
+ * any later call on the pipeline has returned that waited for this ticket. */
+int hsflow_pipeline_submit_device(hsflow_pipeline *pl, const void *d_prev, size_t prev_stride, const void *d_curr,
+                                  size_t curr_stride, const hsflow_params *params, uint64_t *ticket);
+/* wait(ticket) + where that pair's flow lies (hsflow_flow_view_device of its slot): valid until `depth` further
+ * pairs have been submitted.  HSFLOW_E_STATE if the slot has been reused already. */
+int hsflow_pipeline_flow_device(hsflow_pipeline *pl, uint64_t ticket, const float **d_u, const float **d_v, size_t *stride_bytes);
 int hsflow_pipeline_wait(hsflow_pipeline *pl, uint64_t ticket); /* u, v of that pair are complete */
 /* wait(ticket) + iterations_done, last_eps, eps_rerun ... of that pair; HSFLOW_E_STATE once a later
  * pair has finished on the same slot (ask before submitting `depth` more pairs). */

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "hsflow_synchronize": (_i, [_vp]),
     "hsflow_get_flow": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_flow_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
+    "hsflow_flow_view_device": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     "hsflow_get_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_flow_device": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_derivatives": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "hsflow_pipeline_destroy": (_i, [_vp]),
     "hsflow_pipeline_submit": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
     "hsflow_pipeline_submit_ex": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
+    "hsflow_pipeline_submit_device": (_i, [_vp, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
+    "hsflow_pipeline_flow_device": (_i, [_vp, ctypes.c_uint64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     "hsflow_pipeline_wait": (_i, [_vp, ctypes.c_uint64]),
     "hsflow_pipeline_info": (_i, [_vp, ctypes.c_uint64, ctypes.POINTER(HsflowInfo)]),
     "hsflow_pipeline_drain": (_i, [_vp]),

@@ -55,4 +55,26 @@ __global__ __launch_bounds__(256) void k_box_blur3(const uint8_t *__restrict__ s
     *(uint32_t *)(dst + (long long)y * P + x0) = out;
 }
 
+// Both frames of a pair from device memory into the context's planes in ONE launch (hsflow_set_frames_u8_device: a
+// stream of resident pairs pays one copy launch per pair instead of two 2-D copies).  One lane = 16 bytes of one row
+// of either frame (blockIdx.z: which frame); ALIGNED: both sources are 16-byte aligned with strides that are multiples
+// of 16, so whole groups move as one 128-bit access; the ragged end of a row (W % 16) goes byte by byte.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_copy_pair_u8(const uint8_t *__restrict__ srcA, long long strideA,
+                                                      const uint8_t *__restrict__ srcB, long long strideB,
+                                                      uint8_t *__restrict__ dstA, uint8_t *__restrict__ dstB, int W, int H, int P)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 16;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const uint8_t *s = (blockIdx.z ? srcB + (long long)y * strideB : srcA + (long long)y * strideA) + x0;
+    uint8_t *d = (blockIdx.z ? dstB : dstA) + (long long)y * P + x0;
+    if (ALIGNED && x0 + 16 <= W) {
+        *(uint4 *)d = *(const uint4 *)s;
+    } else {
+        const int n = W - x0 < 16 ? W - x0 : 16;
+        for (int k = 0; k < n; k++) d[k] = s[k];
+    }
+}
+
 } // namespace hsk

@@ -825,7 +825,20 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     return HSFLOW_OK;
 }
 
+int solve_impl_inner(hsflow_ctx *c, const hsflow_params *pp, bool async, bool *took_over);
+
 int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
+{
+    // A solve that takes an owed early-stop check over (below) drops it first; should it then fail before it has
+    // registered its own, the owed check comes back -- the flow of the earlier solve is still unverified.
+    const hsflow_ctx::Pending owed = c ? c->pend : hsflow_ctx::Pending();
+    bool took_over = false;
+    const int st = solve_impl_inner(c, pp, async, &took_over);
+    if (st && took_over && !c->pend.active) c->pend = owed;
+    return st;
+}
+
+int solve_impl_inner(hsflow_ctx *c, const hsflow_params *pp, bool async, bool *took_over)
 {
     int st = check_ctx(c, 0);
     if (st) return st;
@@ -836,7 +849,7 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     // not wait for the stream (a caller that streams solves never pays a round trip per solve).
     const bool repeat = c->pend.active && async && !c->force_exact && pp && pp->struct_size == sizeof(hsflow_params) &&
                         !pp->use_previous && std::memcmp(pp, &c->pend.params, sizeof(hsflow_params)) == 0;
-    if (repeat) c->pend.active = false;
+    if (repeat) { c->pend.active = false; *took_over = true; }
     else if ((st = settle_pending(c))) return st;
     c->lastl.valid = false;
     if (!pp || pp->struct_size != sizeof(hsflow_params))

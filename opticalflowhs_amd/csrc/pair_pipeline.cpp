@@ -54,9 +54,9 @@ int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
     info.struct_size = sizeof(info);
     // (without last_eps: an asynchronous ITER|EPS solve measures it only on demand -- hsflow_pipeline_info)
     if ((st = hsflow_get_info_ex(s.ctx, &info, 0))) return ctx_fail(pl, s.ctx, st, "hsflow_get_info_ex");
-    if (info.eps_rerun) { // the solve was repeated exactly: what the queued download copied is stale
+    if (info.eps_rerun && s.u) { // the solve was repeated exactly: what the queued download copied is stale
         if ((st = hsflow_get_flow(s.ctx, 0, s.u, s.us, s.v, s.vs))) return ctx_fail(pl, s.ctx, st, "hsflow_get_flow");
-    }
+    }                            // (a device-resident job keeps its flow in the slot: nothing to copy again)
     s.done = info; s.has_done = true; s.done_ticket = s.ticket;
     return HSFLOW_OK;
 }
@@ -131,6 +131,42 @@ int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *pr
     s.u = u; s.v = v; s.us = us; s.vs = vs;
     if (ticket) *ticket = pl->next;
     pl->next++;
+    return HSFLOW_OK;
+}
+
+int hsflow_pipeline_submit_device(hsflow_pipeline *pl, const void *d_prev, size_t ps, const void *d_curr, size_t cs,
+                                  const hsflow_params *params, uint64_t *ticket)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    if (!params) return pfail(pl, HSFLOW_E_ARG, "params is null");
+    hsflow_pipeline::Slot &s = pl->slots[pl->next % pl->slots.size()];
+    int st = finish_slot(pl, s); // the job that used this slot `depth` submissions ago
+    if (st) return st;
+    if ((st = hsflow_set_frames_u8_device(s.ctx, 0, d_prev, ps, d_curr, cs))) {
+        hsflow_synchronize(s.ctx);
+        return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_device");
+    }
+    if ((st = hsflow_solve_async(s.ctx, params))) {
+        hsflow_synchronize(s.ctx); // the frame copies were queued: do not leave them reading caller memory
+        return ctx_fail(pl, s.ctx, st, "hsflow_solve_async");
+    }
+    s.busy = true;
+    s.ticket = pl->next;
+    s.u = s.v = nullptr; s.us = s.vs = 0; // the flow stays in the slot (hsflow_pipeline_flow_device)
+    if (ticket) *ticket = pl->next;
+    pl->next++;
+    return HSFLOW_OK;
+}
+
+int hsflow_pipeline_flow_device(hsflow_pipeline *pl, uint64_t ticket, const float **du, const float **dv, size_t *stride_bytes)
+{
+    if (!pl) return HSFLOW_E_ARG;
+    if (!du || !dv || !stride_bytes) return pfail(pl, HSFLOW_E_ARG, "null out pointer");
+    int st = hsflow_pipeline_wait(pl, ticket);
+    if (st) return st;
+    hsflow_pipeline::Slot &s = pl->slots[ticket % pl->slots.size()];
+    if (s.busy || !s.has_done || s.done_ticket != ticket) return pfail(pl, HSFLOW_E_STATE, "the slot of that ticket has been reused by a later pair");
+    if ((st = hsflow_flow_view_device(s.ctx, 0, du, dv, stride_bytes))) return ctx_fail(pl, s.ctx, st, "hsflow_flow_view_device");
     return HSFLOW_OK;
 }
 

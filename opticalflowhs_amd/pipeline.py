@@ -29,6 +29,13 @@ def pinned_empty(shape, dtype):
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
+class _DeviceView(object):
+    """fp32 device memory described for torch.as_tensor (zero copy)."""
+
+    def __init__(self, ptr, shape, strides):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "strides": tuple(strides), "version": 2}
+
+
 class PairPipeline(object):
     """`depth` single-pair contexts used round-robin.  Termination: ITER (default) or ITER|EPS."""
 
@@ -73,6 +80,36 @@ class PairPipeline(object):
         self._held.pop(t.value - self.depth, None)  # that slot was waited for inside submit
         self._held[t.value] = (prev, curr, u_out, v_out)
         return t.value
+
+    def submit_device(self, prev, curr, params=None, **kw):
+        """A pair that already lies in device memory (CUDA uint8 tensors of shape (height, width), unit column stride):
+        device-to-device copy into the slot -> solve; the flow stays in the slot (`flow_device`).  The tensors are held
+        until the ticket has been waited for."""
+        for a in (prev, curr):
+            if not (hasattr(a, "is_cuda") and a.is_cuda) or str(a.dtype) != "torch.uint8" or tuple(a.shape) != (self.height, self.width) or a.stride(1) != 1:
+                raise ValueError("device frames must be CUDA uint8 tensors of shape (height, width) with unit column stride")
+        if params is None:
+            kw.setdefault("term_type", TERM_ITER)
+            params = make_params(**kw)
+        t = ctypes.c_uint64()
+        self._check(self._lib.hsflow_pipeline_submit_device(self._h, ctypes.c_void_p(prev.data_ptr()), prev.stride(0), ctypes.c_void_p(curr.data_ptr()),
+                                                            curr.stride(0), ctypes.byref(params), ctypes.byref(t)))
+        self._held.pop(t.value - self.depth, None)
+        self._held[t.value] = (prev, curr)
+        return t.value
+
+    def flow_device(self, ticket, copy=True):
+        """wait(ticket) + that pair's flow as two CUDA tensors of shape (height, width).  copy=False: views of the slot's
+        own planes (row stride = the context's pitch), valid until `depth` more pairs have been submitted."""
+        import torch
+        pu, pv, sb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._lib.hsflow_pipeline_flow_device(self._h, int(ticket), ctypes.byref(pu), ctypes.byref(pv), ctypes.byref(sb)))
+        self._held.pop(int(ticket), None)
+        out = []
+        for p in (pu, pv):
+            view = torch.as_tensor(_DeviceView(p.value, (self.height, self.width), (sb.value, 4)), device="cuda")
+            out.append(view.clone() if copy else view)
+        return tuple(out)
 
     def wait(self, ticket):
         self._check(self._lib.hsflow_pipeline_wait(self._h, int(ticket)))

@@ -282,3 +282,44 @@ def test_repeated_async_iter_eps_solves_pass_the_owed_check_on(hs, oracle, gpu_o
         ctx.solve(lam=0.3, max_iter=30, term_type=ITER)
         u5, v5 = ctx.flow()
         assert np.array_equal(u4, u5) and np.array_equal(v4, v5)
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_device_resident_stream_early_stop_while_the_next_pair_is_in_flight(hs, oracle, gpu_ok, depth):
+    """The reference's camera loop (/root/reference OpticalFlowOpenCV.cpp:91-95: a fresh pair per step, ITER|EPS) through
+    hsflow_pipeline_submit_device: the pairs already lie in device memory, pair k+1 is submitted while pair k's
+    early-stop check is still owed.  Pair kind 0 converges inside the budget (its check fails, the pair is re-solved
+    from its slot's untouched frames), kind 1 does not.  Every pair's flow and stopping sweep must equal the
+    synchronous solve of a plain context, bit for bit, whichever order they are asked for in."""
+    import torch
+    W, H, budget, lam, eps = 512, 160, 400, 1e-3, 1e-4
+    flat_a = np.full((H, W), 90, np.uint8)
+    flat_b = flat_a.copy()
+    flat_a[40:120, 100:400] = 120
+    flat_b[40:120, 100:400] = 121
+    kinds = [(flat_a, flat_b), synth.translating_pair(W, H, seed=11), synth.random_pair(W, H, seed=12)]
+    ref = []
+    with hs.HSFlow(W, H, own_stream=True) as ctx:
+        for A, B in kinds:
+            ctx.set_frames(A, B)
+            i = ctx.solve(lam=lam, max_iter=budget, term_type=3, epsilon=eps)
+            ref.append((ctx.flow(), i["iterations_done"]))
+    assert 1 < ref[0][1] < budget and ref[1][1] == budget, [r[1] for r in ref]   # kind 0 stops early, kind 1 runs the budget out
+    uo, vo, k0, _ = oracle.calc_optical_flow_hs(flat_a, flat_b, lam, budget, epsilon=eps, return_info=True)
+    assert abs(k0 - ref[0][1]) <= 1
+    dev = [(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()) for A, B in kinds]
+    torch.cuda.synchronize()
+    order = [0, 1, 0, 2, 1, 0, 0, 2]
+    p = hs.make_params(lam=lam, max_iter=budget, term_type=3, epsilon=eps, use_graph=True)
+    with hs.PairPipeline(W, H, depth=depth) as pl:
+        tickets = [pl.submit_device(dev[k][0], dev[k][1], params=p) if j < depth else None for j, k in enumerate(order)]
+        for j, k in enumerate(order):
+            # pair j is asked for while pairs j+1 .. j+depth-1 are in flight
+            u, v = pl.flow_device(tickets[j])
+            info = pl.info(tickets[j])
+            assert info["iterations_done"] == ref[k][1] and info["eps_rerun"] == (1 if ref[k][1] < budget else 0), (j, k, info)
+            assert np.array_equal(u.cpu().numpy(), ref[k][0][0]) and np.array_equal(v.cpu().numpy(), ref[k][0][1]), (j, k)
+            if j + depth < len(order):
+                kk = order[j + depth]
+                tickets[j + depth] = pl.submit_device(dev[kk][0], dev[kk][1], params=p)
+        pl.drain()
