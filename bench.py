@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--iter-only", action="store_true", help="headline with ITER termination instead of the reference's ITER|EPS")
     ap.add_argument("--no-side", action="store_true", help="skip the timing of the other termination form (profiling runs)")
     ap.add_argument("--sync-solves", action="store_true", help="hsflow_solve (host waits for every solve) instead of hsflow_solve_async")
+    ap.add_argument("--loop", choices=["auto", "stream", "repeat"], default="auto",
+                    help="what a step is: `stream` = a NEW resident pair every step through the device-resident pair pipeline (two seed pairs "
+                         "alternating; every pair pays its frame copy, derivative pass and its own early-stop check) -- the default for one pair "
+                         "per step with the strip / fold kernels; `repeat` = the same resident batch solved again on one context")
+    ap.add_argument("--stream-depth", type=int, default=2, help="slots of the pair pipeline in the `stream` loop")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the single-thread cpu_baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0: same as --iters)")
@@ -134,7 +139,7 @@ def run_fresh_frames(args, hs, synth, torch, local_rank, W, H, iters, p_ieps, ba
     (hsflow_pipeline_submit_device: frames copied device to device into the slot, pair k+1 enqueued while pair k's
     early-stop check is still owed; the check is looked at when the slot comes round again).  Every step pays its own
     frame copy, derivative pass and early-stop check -- nothing is carried over between steps."""
-    depth = 3
+    depth = args.stream_depth
     seeds = []
     for sd in (1, 2):
         A, B = synth.translating_pair(W, H, seed=sd)
@@ -325,6 +330,43 @@ def main():
         args.iter_only, args.no_side = True, True
     head_p, side_p = (p_iter, p_ieps) if args.iter_only else (p_ieps, p_iter)
     head_name, side_name = ("ITER", "ITER|EPS (eps 1e-6)") if args.iter_only else ("ITER|EPS (eps 1e-6)", "ITER")
+    # What a step is.  `stream`: the reference's camera loop (OpticalFlowOpenCV.cpp:91-95 -- a NEW pair every step) with the
+    # pairs resident in HBM: two seed pairs alternate through hsflow_pipeline_submit_device; pair k+1 is enqueued on the next
+    # slot's stream while pair k's early-stop check is still owed, and nothing is carried over from one step to the next.
+    # `repeat`: the same resident batch solved again and again on one context (rounds 1-2's loop; kept as `single_context`).
+    loop = args.loop
+    if loop == "auto":
+        loop = "stream" if (pairs == 1 and args.kernel in ("auto", "strip", "fold") and not args.sync_solves and not args.no_graph) else "repeat"
+    pl = None
+    if loop == "stream":
+        if pairs != 1:
+            sys.stderr.write("bench.py: --loop stream runs one pair per step\n")
+            sys.exit(2)
+        s0 = 1 if world == 1 else 1000 + 2 * rank
+        dev_pairs = [(torch.from_numpy(frames[0]).to("cuda:%d" % local_rank), torch.from_numpy(frames[1]).to("cuda:%d" % local_rank))]
+        A2, B2 = synth.translating_pair(W, H, seed=s0 + 1)
+        dev_pairs.append((torch.from_numpy(A2).to("cuda:%d" % local_rank), torch.from_numpy(B2).to("cuda:%d" % local_rank)))
+        torch.cuda.synchronize()
+        pl = hs.PairPipeline(W, H, depth=args.stream_depth, device=local_rank)
+        n_sub = [0]
+
+        def stepper(p):  # noqa: F811 -- the stream loop's step: submit the next pair (blocks only while its slot is still busy)
+            def step():
+                a, b = dev_pairs[n_sub[0] & 1]
+                n_sub[0] += 1
+                return pl.submit_device(a, b, params=p)
+            return step
+
+        def timed_block(step):  # noqa: F811 -- K submissions, then everything in flight drained, inside the bracket
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            pl.drain()
+            torch.cuda.synchronize()
+            barrier()
+            return reduce_max(time.perf_counter() - t0)
     step = stepper(head_p)
     # Warm-up: --warmup untimed steps, and further untimed steps until WARM_SECONDS have passed -- an idle MI355X needs
     # ~30 ms of back-to-back work to reach the clock it then holds (profiles/r02_clock_ramp.txt: 0.196 -> 0.175 ms per
@@ -341,7 +383,8 @@ def main():
 
     # THE timed region of the contract: exactly --steps steps between barrier + synchronize, max over ranks
     elapsed = timed_block(step)
-    info = ctx.info()   # (settles the last solve's early-stop check: iterations_done / eps_rerun are final)
+    # (settles the last solve's early-stop check: iterations_done / eps_rerun are final)
+    info = pl.info(step()) if pl else ctx.info()
     # spread: the same block again, --blocks - 1 more times
     block_ms = [elapsed / args.steps * 1e3] + [timed_block(step) / args.steps * 1e3 for _ in range(max(0, args.blocks - 1))]
     # the other termination form beside it (same steps, same block structure)
@@ -351,7 +394,32 @@ def main():
         for _ in range(min(args.warmup, 5)):
             step2()
         side_ms = [timed_block(step2) / args.steps * 1e3 for _ in range(max(1, min(args.blocks, 3)))]
-        info2 = ctx.info()
+        info2 = pl.info(step2()) if pl else ctx.info()
+    # rounds 1-2's loop beside the stream: the SAME pair solved again and again on one context (an asynchronous ITER|EPS
+    # solve that repeats the owed one bit for bit takes its early-stop check over, one check is settled at the end)
+    single = None
+    if pl is not None:
+        pl.drain()
+        single = {"what": "the same resident pair solved again and again on ONE context through hsflow_solve_async (one stream; an ITER|EPS "
+                          "solve that repeats the owed one takes its early-stop check over -- no check settled inside the timed region)"}
+        if not args.no_side:
+            for nm, pp_ in (("ITER|EPS (eps 1e-6)", p_ieps), ("ITER", p_iter)):
+                st_ = (lambda q: (lambda: ctx.solve_async(q)))(pp_)
+                for _ in range(20):
+                    st_()
+                ms_ = []
+                for _ in range(max(1, min(args.blocks, 3))):
+                    barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        st_()
+                    torch.cuda.synchronize()
+                    barrier()
+                    ms_.append(reduce_max(time.perf_counter() - t0) / args.steps * 1e3)
+                single[nm] = {"ms_per_step": statistics.median(ms_), "ms_per_step_blocks": ms_,
+                              "value": world * W * H * iters / (statistics.median(ms_) * 1e-3) / 1e6}
+            ctx.synchronize()
 
     # Per-kernel durations with HIP events on the launch stream: eager launches of the same solve bracketed by
     # hipEventRecord inside the C ABI (params.profile).  Events between graph nodes would perturb the timed
@@ -420,6 +488,10 @@ def main():
     roof["fp32_vector"]["frac"] = roof["fp32_vector"]["achieved_TFLOPs"] / FP32_VECTOR_PEAK_TFLOPS
     if multi:
         roof.update({"achieved": achieved_valu, "peak": peak_measured, "unit": "Tlane-op/s", "frac": achieved_valu / peak_measured})
+        # `frac` prices the kernel alone on the chip (HIP events around eager launches on one stream, what rocprofv3 sees too);
+        # in the stream loop two slots' launches overlap (one pair's load phase and launch gaps under the other's sweeps), so
+        # the chip gets through a step in less than the sum of its kernels' own durations:
+        roof["valu_issue"]["frac_at_step_rate"] = ideal_us_per_step / (ms_per_step * 1e3)
     else:
         roof.update({"achieved": alg_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbps / HBM_PEAK_GBS})
 
@@ -447,18 +519,24 @@ def main():
         "warmup_steps_run": n_warm,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, %s termination"
-                               % (W, H, pairs, args.lam, iters, head_name),
+        "config": {"workload": ("a stream of %dx%d translating-texture pairs resident in HBM, a new pair every step (two seed pairs alternating), "
+                                "lambda %g, %d Jacobi iterations, %s termination" % (W, H, args.lam, iters, head_name)) if pl else
+                               ("%dx%d translating-texture pair(s), %d pair(s) per GPU per step, lambda %g, %d Jacobi iterations, %s termination"
+                                % (W, H, pairs, args.lam, iters, head_name)),
                    "width": W, "height": H, "iters": iters, "pairs_per_gpu": pairs, "lambda": args.lam,
                    "kernel": KNAME[info["kernel"]],
                    "fuse_steps": info["fuse_steps"], "tile": [info["tile_w"], info["tile_h"]],
                    "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"],
                    "lds_bytes": info["lds_bytes"], "hipgraph": not args.no_graph, "termination": head_name,
-                   "call": "hsflow_solve" if args.sync_solves else "hsflow_solve_async",
+                   "loop": loop,
+                   "call": ("hsflow_pipeline_submit_device, %d slots (one stream each)" % args.stream_depth) if pl else
+                           ("hsflow_solve" if args.sync_solves else "hsflow_solve_async"),
                    "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"],
-                   "eps_check": "n/a (ITER)" if args.iter_only else ("settled per solve (hsflow_solve)" if args.sync_solves else
-                                 "carried over identical repeats: every step solves the SAME resident pair, so a step takes over the early-stop "
-                                 "check the previous one owes and one check is settled after the timed region; a new pair per step is `fresh_frames`"),
+                   "eps_check": "n/a (ITER)" if args.iter_only else (
+                       "every pair's own check: witness words reduced and read when the pair's slot comes round again, a pair whose early stop fired "
+                       "is re-solved from its slot's frames" if pl else "settled per solve (hsflow_solve)" if args.sync_solves else
+                       "carried over identical repeats: every step solves the SAME resident pair, so a step takes over the early-stop "
+                       "check the previous one owes and one check is settled after the timed region; a new pair per step is `fresh_frames`"),
                    "sharding": "independent pairs per rank, no collective"},
         "ms_per_step_blocks": block_ms, "ms_per_step_min": min(block_ms), "ms_per_step_median": statistics.median(block_ms),
         "ms_per_step_max": max(block_ms),
@@ -494,7 +572,14 @@ def main():
         except RuntimeError:
             pass
     # the reference's camera loop: a new pair every step, ITER|EPS, nothing carried over between steps
-    if not args.no_side and args.kernel == "auto" and pairs == 1 and not args.iter_only:
+    if pl is not None:
+        out["single_context"] = single
+        if not args.iter_only:  # the headline IS that loop
+            out["fresh_frames"] = {"is_the_headline": True, "ms_per_step": ms_per_step, "value": value, "unit": "Mpix*iter/s", "depth": args.stream_depth,
+                                   "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"],
+                                   "what": "a different resident pair every step, ITER|EPS (eps 1e-6), hsflow_pipeline_submit_device"}
+        pl.close()
+    elif not args.no_side and args.kernel == "auto" and pairs == 1 and not args.iter_only:
         try:
             out["fresh_frames"] = run_fresh_frames(args, hs, synth, torch, local_rank, W, H, iters, p_ieps, barrier, reduce_max, world)
         except hs.HsflowError as e:

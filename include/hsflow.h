@@ -158,6 +158,14 @@ int hsflow_destroy(hsflow_ctx *ctx); /* NULL is accepted; idempotent per handle 
  * compute bit for bit what the whole-frame solve computes for the same pixels.  Default 0. */
 int hsflow_set_row_origin(hsflow_ctx *ctx, int first_row);
 
+/* The launch planners count on `compute_units` CUs instead of the whole chip (0: the whole chip again).  For a context
+ * whose solves run BESIDE other contexts' solves -- the slots of a pair pipeline do this by themselves, with
+ * CUs / depth -- so that each solve takes the shape that costs the least CU-time (few large tiles, little halo
+ * redundancy) rather than the one that spreads a small frame over every CU to shorten its own latency: at the reference's
+ * 600x480 default (main.cpp:4-8) that is the difference between 210 tiles of 88x16 and 36 of 216x40 per launch.
+ * Results are bit-identical whatever the shape. */
+int hsflow_set_cu_share(hsflow_ctx *ctx, int compute_units);
+
 /* --- frames in ---------------------------------------------------------------------------- */
 
 /* Host u8 single-channel frames, row strides in bytes (>= width).  Synchronous. */

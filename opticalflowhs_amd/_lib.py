@@ -51,6 +51,7 @@ PROTOTYPES = {
     "hsflow_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i]),
     "hsflow_destroy": (_i, [_vp]),
     "hsflow_set_row_origin": (_i, [_vp, _i]),
+    "hsflow_set_cu_share": (_i, [_vp, _i]),
     "hsflow_set_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),

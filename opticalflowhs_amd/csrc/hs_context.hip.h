@@ -82,6 +82,7 @@ struct hsflow_ctx {
     bool persist_off = false;    // a persistent launch timed out on this context: not used again
     bool persist_unchecked = false; // an asynchronous persistent solve whose error word has not been looked at yet
     bool counted = false;        // this context is in g_live_ctx
+    int cu_share = 0;            // > 0: the planners count on this many CUs only (hsflow_set_cu_share); 0: the whole chip
     int num_cu = 0;              // compute units of the device (one workgroup of the persistent launch per CU)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
     size_t scratch_bytes = 0;

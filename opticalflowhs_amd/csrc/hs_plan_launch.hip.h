@@ -3,6 +3,14 @@
 #pragma once
 
 namespace {
+// How many compute units the planners count on.  A context that shares the device with other contexts' solves in flight
+// (the slots of a pair pipeline: hsflow_set_cu_share) plans for its share of the chip: the shapes that minimise the
+// CU-time of a solve -- few large tiles, little halo redundancy -- instead of those that spread one small frame thinly
+// over all 256 CUs to shorten ITS latency while the other solves wait.  With a share the launch has no round structure
+// of its own (its workgroups start wherever a CU falls free), so the cost models then count fractional rounds.
+int plan_cus(const hsflow_ctx *c) { return c->cu_share > 0 ? c->cu_share : kNumCU; }
+bool plan_shared(const hsflow_ctx *c) { return c->cu_share > 0 && c->cu_share < kNumCU; }
+
 // ------------------------------------------------------------------------------------------
 // Tile planner for the fused kernel.  Cost model: the launch takes ceil(tiles / CUs) rounds of
 // one workgroup per CU; a round costs the region area (LDS sweeps dominate) plus a fixed part.
@@ -33,7 +41,8 @@ bool make_plan(const hsflow_ctx *c, int T, int tw, int th, int nt, FusedPlan &be
                 const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
                 const long long tiles = (long long)tx * ty * c->N;
                 const int K = (int)((G + NT - 1) / NT);
-                const long long rounds = (tiles + (long long)kNumCU * wg_per_cu - 1) / ((long long)kNumCU * wg_per_cu);
+                const long long ncu = plan_cus(c);
+                const long long rounds = (tiles + ncu * wg_per_cu - 1) / (ncu * wg_per_cu);
                 // per-round cost ~ K sweeps-worth of work per lane * T, plus load/store of the tile
                 const double per_round = (double)K * NT * 4 * (T + 3.0) + 2000.0;
                 const double cost = (double)rounds * per_round;
@@ -171,8 +180,10 @@ double classic_strip_launch_us(const hsflow_ctx *c, const hsk::ClassicStripGeom 
     const int NW = g.NW, lds = NW * 8192;
     const int wg_per_cu = std::max(1, std::min(kLdsLimit / lds, classic_strip_max_waves(R) / NW));
     if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
-    const double rounds = std::ceil((double)tiles / ((double)kNumCU * wg_per_cu));
-    const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // workgroups sharing a CU
+    const int ncu = plan_cus(c);
+    const double rr = (double)tiles / ((double)ncu * wg_per_cu);
+    const double rounds = plan_shared(c) ? std::max(1.0, rr) : std::ceil(rr); // (a share of the chip: no round structure, see plan_cus)
+    const long long conc = std::min<long long>(wg_per_cu, (tiles + ncu - 1) / ncu); // workgroups sharing a CU
     const double wps = (double)((NW + 3) / 4) * (double)conc;                              // wavefronts on the busiest SIMD
     const double rps = wps * R;                                                              // ... and their rows
     // per row and sweep: 0.176 us for the shapes that divide with the precomputed reciprocal (R = 2, 3, 4, 6), 0.2 for the
@@ -271,8 +282,9 @@ hipError_t launch_classic_strip(const hsflow_ctx *c, const ClassicStripPlan &p, 
 int strip_max_waves(int R, int fold) { const int r = fold ? R + 1 : R; return r <= 5 ? 16 : (r <= 6 ? 12 : 8); }
 
 
-double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double image_pixels, int *wg_per_cu_out = nullptr)
+double strip_launch_cost(const hsflow_ctx *c, int T, int R, int NW, long long tiles, int fold, double image_pixels, int *wg_per_cu_out = nullptr)
 {
+    const int ncu = plan_cus(c);
     // Parameters fitted (least squares on log time, rms 8 %) to profiles/r01_sweep_1080p_strip5.csv,
     // r01_sweep_4k_b.csv and r01_sweep_batch16.csv.  The sweep is VALU-issue bound (~34 instructions
     // per row per wavefront, ~4.2 cycles each per SIMD with 4 resident wavefronts, more with fewer);
@@ -281,8 +293,8 @@ double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double
     const int lds = NW * (fold ? 4096 : 8192);
     const int wg_per_cu = std::max(1, std::min(std::min(kLdsLimit / lds, (per_simd * 4) / NW), 8));
     if (wg_per_cu_out) *wg_per_cu_out = wg_per_cu;
-    const long long slots = (long long)kNumCU * wg_per_cu;
-    const long long conc = std::min<long long>(wg_per_cu, (tiles + kNumCU - 1) / kNumCU); // WGs sharing a CU
+    const long long slots = (long long)ncu * wg_per_cu;
+    const long long conc = std::min<long long>(wg_per_cu, (tiles + ncu - 1) / ncu); // WGs sharing a CU
     const double wps = (double)(conc * NW) / 4.0;                                          // wavefronts per SIMD
     const double cpi = wps >= 3.5 ? 4.2 : (wps >= 2.5 ? 5.6 : (wps >= 1.5 ? 6.5 : 8.0));
     const int rows_per_lane = fold ? 2 * R : R;
@@ -294,7 +306,7 @@ double strip_launch_cost(int T, int R, int NW, long long tiles, int fold, double
     double load = 2050.0 + 0.4 * 256.0 * R * NW * conc;
     if (conc > 1) load *= 0.4; // another workgroup's sweeps hide part of it
     const double r = (double)tiles / (double)slots;
-    const double rounds = conc == 1 ? std::ceil(r) : std::max(1.0, r + 0.7);
+    const double rounds = plan_shared(c) ? std::max(1.0, r) : conc == 1 ? std::ceil(r) : std::max(1.0, r + 0.7);
     return 6000.0 + 6e-4 * 8.0 * image_pixels + rounds * (load + T * sweep);
 }
 
@@ -316,7 +328,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
             if (lds > kLdsLimit) continue;
             const int tx = (W + CW - 1) / CW, ty = (H + CH - 1) / CH;
             const long long tiles = (long long)tx * ty * c->N;
-            const double cost = strip_launch_cost(T, R, NW, tiles, fold, (double)W * H * c->N);
+            const double cost = strip_launch_cost(c, T, R, NW, tiles, fold, (double)W * H * c->N);
             if (cost < best_cost - 1e-9) {
                 best_cost = cost;
                 found = true;
@@ -337,7 +349,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
 
 // Sweeps per launch for a budget of `iters` sweeps: minimise the modelled time of the whole solve
 // (full launches of T plus one tail launch of iters % T).
-int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fold)
+int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fold, double *total_out = nullptr)
 {
     double best = 1e300;
     int bestT = 1;
@@ -350,6 +362,7 @@ int pick_strip_T(const hsflow_ctx *c, int iters, const hsflow_params &p, int fol
         const double total = (iters / T) * cfull + (rem ? ctail : 0.0);
         if (total < best) { best = total; bestT = T; }
     }
+    if (total_out) *total_out = best;
     return bestT;
 }
 

@@ -759,7 +759,15 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     // AUTO: the register-strip kernel; below ~1.5 Mpixel per context its folded form (128-column strips:
     // twice the tiles across, so small frames reach more CUs -- measured 5-25 % faster from 160x120 to
     // 1600x900 at 100 sweeps, tools/crossover.py).
-    const bool small_frame = (long long)c->W * c->H * c->N <= 1500000LL;
+    bool small_frame = (long long)c->W * c->H * c->N <= 1500000LL;
+    // A context that plans for a share of the chip (hsflow_set_cu_share: pair pipeline slots) wants the cheaper of the two
+    // in CU-time, whatever the frame size: the folded kernel's 128-column strips pay twice the column halo.
+    if (plan_shared(c) && p.kernel == HSFLOW_KERNEL_AUTO && (p.term_type & HSFLOW_TERM_ITER) && p.max_iter > 0 && p.max_iter <= (1 << 16) && p.fuse_steps <= 0) {
+        double cs = 1e300, cf = 1e300;
+        pick_strip_T(c, p.max_iter, p, 0, &cs);
+        pick_strip_T(c, p.max_iter, p, 1, &cf);
+        small_frame = cf < cs;
+    }
     // PERSIST is the strip kernel as one launch per solve; AUTO takes it where it can run (persist_obstacle)
     const bool persist_asked = p.kernel == HSFLOW_KERNEL_PERSIST;
     const int kernel = persist_asked ? HSFLOW_KERNEL_STRIP

@@ -181,6 +181,19 @@ int hsflow_set_row_origin(hsflow_ctx *c, int first_row)
     return HSFLOW_OK;
 }
 
+int hsflow_set_cu_share(hsflow_ctx *c, int compute_units)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if (compute_units < 0) return fail(c, HSFLOW_E_ARG, "compute_units must be >= 0 (0: the whole chip)");
+    const int share = compute_units >= kNumCU ? 0 : compute_units;
+    if (share != c->cu_share) {
+        if ((st = settle_pending(c))) return st;
+        c->cu_share = share; // (graphs are keyed by the launch shape, so cached ones stay valid)
+    }
+    return HSFLOW_OK;
+}
+
 int hsflow_destroy(hsflow_ctx *c)
 {
     if (!c) return HSFLOW_OK;

@@ -8,6 +8,7 @@
 // C ABI, so it is also the example of how a host drives several contexts from one thread.
 #include "../../include/hsflow.h"
 
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -79,6 +80,15 @@ int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int hei
             g_pipeline_create_error = std::string("hsflow_create: ") + hsflow_last_error(nullptr);
             hsflow_pipeline_destroy(pl);
             return st;
+        }
+        // HSFLOW_PIPELINE_CU_SHARE=<n>: every slot plans for n CUs (hsflow_set_cu_share) -- an experiment knob.  Off by
+        // default: the planners' cost models were fitted to solves that have the chip to themselves, and with a share
+        // they picked worse shapes than without at 1080p (0.161 against 0.139 ms per pair at depth 2) and at 600x480
+        // (0.097 against 0.082), while a hand-picked large-tile shape does win at 600x480 / depth 8 (0.053 against 0.077:
+        // profiles/r03_pipeline_shapes.txt).  A caller that knows its stream passes that shape in the params.
+        if (const char *ov = getenv("HSFLOW_PIPELINE_CU_SHARE")) {
+            const int share = atoi(ov);
+            if (share > 0) hsflow_set_cu_share(s.ctx, share);
         }
     }
     *out = pl;
