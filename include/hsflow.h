@@ -166,6 +166,24 @@ int hsflow_set_row_origin(hsflow_ctx *ctx, int first_row);
  * Results are bit-identical whatever the shape. */
 int hsflow_set_cu_share(hsflow_ctx *ctx, int compute_units);
 
+/* --- building blocks for drivers that run ONE solve over several contexts (row slabs, hsflow_slab_*) ----------- */
+
+/* Only the changes of rows [first_row, first_row + rows) count for Eps and for the witness of ITER|EPS solves (rows <= 0:
+ * the whole frame again).  A row slab sets its OWNED rows: its halo rows repeat the neighbour's and go stale towards
+ * the slab's edge inside a chunk, so their changes say nothing about the frame's Eps
+ * (cv210.dll@0x1012ed2f-0x1012eda5 takes the maximum over the frame).  Strip and simple kernels. */
+int hsflow_set_eps_rows(hsflow_ctx *ctx, int first_row, int rows);
+/* Exactly params->max_iter sweeps (whatever params->term_type says: nothing stops them) with the Eps of every sweep
+ * -- over the rows of hsflow_set_eps_rows -- written to sweep_eps[0 .. max_iter).  Synchronous.  What a driver needs to
+ * find the stopping sweep of a solve that is spread over several contexts: Eps_k of the frame = the maximum of the
+ * contexts' Eps_k. */
+int hsflow_solve_probe(hsflow_ctx *ctx, const hsflow_params *params, float *sweep_eps);
+/* The early-stop check an asynchronous ITER|EPS solve still owes, looked at WITHOUT acting on it: waits for the stream;
+ * *proven = 1 if the witness words prove that Eps stayed >= epsilon in every sweep (over the rows of
+ * hsflow_set_eps_rows), 0 if they do not -- the flow of the whole budget stands either way and nothing is re-run.  A
+ * proof from ANY context of a spread solve covers the frame (its Eps is the maximum).  HSFLOW_E_STATE if nothing is owed. */
+int hsflow_take_verdict(hsflow_ctx *ctx, int *proven);
+
 /* --- frames in ---------------------------------------------------------------------------- */
 
 /* Host u8 single-channel frames, row strides in bytes (>= width).  Synchronous. */
@@ -336,8 +354,15 @@ const char *hsflow_multi_last_error(hsflow_multi *m); /* m may be NULL: create()
  * neighbouring slabs swap `halo` rows of u and v device to device (peer copies over xGMI, ordered by events; the host
  * only enqueues) -- k-row halos every k sweeps instead of one row per sweep: the same bytes in k times fewer
  * messages.  The result is bit-identical to the whole-frame solve on one GPU (hsflow_set_row_origin keeps each slab
- * on the frame's checkerboard).  ITER termination, zero start.  A device may be listed more than once.  The
- * one-process-per-GPU form of the same scheme, with RCCL send / recv, is opticalflowhs_amd/slab.py. */
+ * on the frame's checkerboard).  Termination: ITER, or ITER|EPS as the reference calls the solver
+ * (OpticalFlowOpenCV.cpp:29,94 -- hsflow_default_params as they are): the frame's Eps is the maximum over the slabs'
+ * owned rows, so a chunk that ANY slab's witness vouches for holds no stop; when none does, the solve is replayed to
+ * that chunk and measured sweep by sweep, the maximum taken on the host between chunks, and it ends on the sweep the
+ * one-context solve ends on.  use_previous continues from the flow of the last solve (halos refreshed first).  A
+ * device may be listed more than once -- listing each device TWICE gives every GPU two sub-slabs on streams of their
+ * own, so that one's peer copies run under the other's sweeps (hsflow_slab_create_overlapped does that).  The
+ * one-process-per-GPU form of the same scheme, with RCCL send / recv, is opticalflowhs_amd/slab.py.
+ * The cross-device copies (hipMemcpyPeerAsync) have only ever run between slabs that share a card (one-GPU boxes). */
 typedef struct hsflow_slab hsflow_slab;
 int hsflow_slab_create(hsflow_slab **out, const int *devices, int nslab, int width, int height, int halo);
 int hsflow_slab_destroy(hsflow_slab *s); /* NULL accepted */
@@ -346,6 +371,10 @@ int hsflow_slab_rows(hsflow_slab *s, int k, int *lo, int *hi); /* rows [lo, hi) 
 int hsflow_slab_set_frames_u8(hsflow_slab *s, const uint8_t *prev, size_t prev_stride, const uint8_t *curr, size_t curr_stride);
 int hsflow_slab_solve(hsflow_slab *s, const hsflow_params *params); /* returns after every device finished */
 int hsflow_slab_exchanges(hsflow_slab *s);                          /* halo exchanges of the last solve */
+int hsflow_slab_iterations_done(hsflow_slab *s);                    /* sweeps of the last solve (< max_iter: the early stop fired) */
+int hsflow_slab_eps_measured(hsflow_slab *s);                       /* 1: no slab's witness held, Eps was measured sweep by sweep */
+/* 2 * ndev slabs, devices[k] holding slabs 2k and 2k+1 (see above). */
+int hsflow_slab_create_overlapped(hsflow_slab **out, const int *devices, int ndev, int width, int height, int halo);
 int hsflow_slab_get_flow(hsflow_slab *s, float *u, size_t u_stride, float *v, size_t v_stride);
 const char *hsflow_slab_last_error(hsflow_slab *s); /* s may be NULL: create() error */
 

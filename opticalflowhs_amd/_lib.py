@@ -52,6 +52,9 @@ PROTOTYPES = {
     "hsflow_destroy": (_i, [_vp]),
     "hsflow_set_row_origin": (_i, [_vp, _i]),
     "hsflow_set_cu_share": (_i, [_vp, _i]),
+    "hsflow_set_eps_rows": (_i, [_vp, _i, _i]),
+    "hsflow_solve_probe": (_i, [_vp, _pp, ctypes.POINTER(ctypes.c_float)]),
+    "hsflow_take_verdict": (_i, [_vp, ctypes.POINTER(_i)]),
     "hsflow_set_frames_u8": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_set_frames_u8_device": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
@@ -107,6 +110,9 @@ PROTOTYPES = {
     "hsflow_slab_set_frames_u8": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "hsflow_slab_solve": (_i, [_vp, _pp]),
     "hsflow_slab_exchanges": (_i, [_vp]),
+    "hsflow_slab_iterations_done": (_i, [_vp]),
+    "hsflow_slab_eps_measured": (_i, [_vp]),
+    "hsflow_slab_create_overlapped": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i]),
     "hsflow_slab_get_flow": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "hsflow_slab_last_error": (ctypes.c_char_p, [_vp]),
     "hsflow_calc_optical_flow_hs_8u32f": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i,

@@ -82,6 +82,8 @@ struct hsflow_ctx {
     bool persist_off = false;    // a persistent launch timed out on this context: not used again
     bool persist_unchecked = false; // an asynchronous persistent solve whose error word has not been looked at yet
     bool counted = false;        // this context is in g_live_ctx
+    int eps_row0 = 0, eps_rows = 0; // hsflow_set_eps_rows: rows whose changes count for Eps (0 rows: the whole frame)
+    std::vector<float> sweep_eps;   // Eps of every sweep of the last exact (per-sweep) pass: hsflow_solve_probe hands it out
     int cu_share = 0;            // > 0: the planners count on this many CUs only (hsflow_set_cu_share); 0: the whole chip
     int num_cu = 0;              // compute units of the device (one workgroup of the persistent launch per CU)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back

@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
                                                        float *__restrict__ u_out,
                                                        float *__restrict__ v_out, int W, int H,
                                                        int P, long long plane, float ilambda,
-                                                       unsigned *__restrict__ eps_out, int org)
+                                                       unsigned *__restrict__ eps_out, int org, int ey0, int ey1)
 {
+    // ey0, ey1: rows whose changes count for Eps (hsflow_set_eps_rows; the whole frame by default)
     // org: frame row of this context's row 0, modulo 2 (row slabs: the checkerboard of update_cv is the whole frame's)
     // ZERO: the incoming flow is identically zero (first sweep of a solve): nothing is read
     // EPS: eps_out[0] receives max |new - old| of this sweep (atomicMax on the float's bit pattern)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_jacobi_simple(const uint32_t *__restric
             const bool last = (x0 + k >= W - 1);
             const float uR = last ? wu[k + 1] : wu[k + 2], vR = last ? wv[k + 1] : wv[k + 2];
             update_cv((k + y + org) & 1, wu[k], uR, au[k], bu[k], wv[k], vR, av[k], bv[k], al, be, ga, nu[k], nv[k]); // x0 % 4 == 0
-            if (EPS && x0 + k < W)
+            if (EPS && x0 + k < W && y >= ey0 && y < ey1)
                 e = fmaxf(e, fmaxf(fabsf(wu[k + 1] - nu[k]), fabsf(wv[k + 1] - nv[k])));
         }
         *(float4 *)(u_out + rc) = make_float4(nu[0], nu[1], nu[2], nu[3]);

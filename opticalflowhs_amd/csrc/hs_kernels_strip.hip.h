@@ -65,6 +65,8 @@ struct StripGeom {
     int tiles_x, tiles_y;
     int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
     int org;            // frame row of this context's row 0, modulo 2 (row slabs; checkerboard phase of update_cv)
+    int ey0, ey1;       // rows [ey0, ey1) of the context whose changes count for Eps and the witness (hsflow_set_eps_rows: a row slab's
+                        // owned rows -- its halo rows repeat a neighbour's, stale towards the slab's edge); the strip kernel only
 };
 
 // index of the even reflection: ..., 1, 0 | 0, 1, ..., n-1 | n-1, n-2, ...
@@ -448,6 +450,14 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
+    unsigned epscore = 0; // the core rows that lie in the Eps window (wave-uniform; all of them unless hsflow_set_eps_rows narrowed it)
+    if (EPS != 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int y = y0 + img_row(r);
+            if (((rowcore >> r) & 1u) && y >= g.ey0 && y < g.ey1) epscore |= 1u << r;
+        }
+    }
     if (DERIV && lanecore) { // the cores tile the image: this launch leaves the complete derivative plane behind
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -466,7 +476,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
             if (HS_DIAG & 8) uP[r] += SC.uP + SP.uP;                                               \
             else strip_row_update<PE>(uP[r], uQ[r], vP[r], vQ[r], SC, SP, cf[r]);                  \
             if (EM == 1) {                                                                         \
-                if ((rowcore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
+                if ((epscore >> (r)) & 1u) { /* wave-uniform; lanes outside the core are masked once per sweep */ \
                     const f2 dUP = HS_DIFF(ouP, uP[r]), dUQ = HS_DIFF(ouQ, uQ[r]), dVP = HS_DIFF(ovP, vP[r]), dVQ = HS_DIFF(ovQ, vQ[r]); \
                     if (!xedge) { /* workgroup-uniform: every column of the region is an image column */ \
                         e = fmaxf(fmaxf(e, fabsf(dUP.x)), fabsf(dUP.y));                           \
@@ -518,7 +528,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     const int wd = rev ? wa : wb, sd = rev ? sa : sb;
     int seen_n = 0; // EPS == 2, wave-uniform: sweeps so far that had a change >= eps_thr (a counter: a
                     // loop-carried flag makes the register allocator spill inside the loop)
-    const unsigned long long wit_mask = (rowcore & 1u) ? __builtin_amdgcn_ballot_w64(lanecore) : 0ull; // lanes whose answer counts
+    const unsigned long long wit_mask = (epscore & 1u) ? __builtin_amdgcn_ballot_w64(lanecore) : 0ull; // lanes whose answer counts
     // Who looks, and when: the wavefronts whose rows are all core rows take turns, one of them per sweep (a sweep
     // needs ONE witness in the workgroup; sixteen wavefronts looking in every sweep cost 4 % of the launch).  A
     // workgroup without such a wavefront (thin cores, clipped bottom tiles) keeps the old rule: every wavefront whose

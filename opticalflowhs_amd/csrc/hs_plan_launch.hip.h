@@ -8,6 +8,11 @@ namespace {
 // CU-time of a solve -- few large tiles, little halo redundancy -- instead of those that spread one small frame thinly
 // over all 256 CUs to shorten ITS latency while the other solves wait.  With a share the launch has no round structure
 // of its own (its workgroups start wherever a CU falls free), so the cost models then count fractional rounds.
+// rows whose changes count for Eps / the witness (hsflow_set_eps_rows; the whole frame unless narrowed)
+int eps_row0(const hsflow_ctx *c) { return c->eps_rows > 0 ? c->eps_row0 : 0; }
+int eps_row1(const hsflow_ctx *c) { return c->eps_rows > 0 ? c->eps_row0 + c->eps_rows : c->H; }
+bool eps_windowed(const hsflow_ctx *c) { return c->eps_rows > 0 && (c->eps_row0 > 0 || c->eps_rows < c->H); }
+
 int plan_cus(const hsflow_ctx *c) { return c->cu_share > 0 ? c->cu_share : kNumCU; }
 bool plan_shared(const hsflow_ctx *c) { return c->cu_share > 0 && c->cu_share < kNumCU; }
 
@@ -340,6 +345,7 @@ bool make_strip_plan(const hsflow_ctx *c, int T, int rows, int threads, int fold
                 g.W = W; g.H = H; g.P = c->P; g.plane = c->plane;
                 g.T = T; g.HX = HX; g.CW = CW; g.CH = CH; g.NW = NW;
                 g.tiles_x = tx; g.tiles_y = ty; g.zero_in = 0; g.org = c->org;
+                g.ey0 = eps_row0(c); g.ey1 = eps_row1(c);
             }
         }
     }
@@ -662,7 +668,7 @@ hipError_t launch_simple(const hsflow_ctx *c, bool eps, const float *ui, const f
     const dim3 grid((c->W + 255) / 256, (c->H + 3) / 4, c->N), block(64, 4);
 #define HS_SIMPLE(E, Z)                                                                            \
     hipLaunchKernelGGL((hsk::k_jacobi_simple<E, Z>), grid, block, 0, c->stream, c->dCoef, ui, vi, uo, vo, \
-                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr, c->org)
+                       c->W, c->H, c->P, c->plane, coeff, c->epsPtr, c->org, eps_row0(c), eps_row1(c))
     if (eps) { if (zero_in) HS_SIMPLE(true, true); else HS_SIMPLE(true, false); }
     else { if (zero_in) HS_SIMPLE(false, true); else HS_SIMPLE(false, false); }
 #undef HS_SIMPLE

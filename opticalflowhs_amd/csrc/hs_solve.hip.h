@@ -20,7 +20,9 @@ int check_persist(hsflow_ctx *c)
                                     "this context now launches per fuse_steps iterations, solve again");
 }
 
-int settle_pending(hsflow_ctx *c)
+// verdict_only: report whether the witness words prove "no early stop" and leave it at that (no exact pass; the flow of
+// the whole budget stands) -- for a driver that decides over several contexts (row slabs: hsflow_take_verdict).
+int settle_pending(hsflow_ctx *c, int *verdict_only = nullptr)
 {
     if (!c->pend.active) return HSFLOW_OK;
     c->pend.active = false;
@@ -42,6 +44,13 @@ int settle_pending(hsflow_ctx *c)
     if (!gave_up && witness_proven(c->hEps, c->pend.slots, c->pend.params.epsilon, &last, false)) {
         c->info.iterations_done = c->pend.iters;
         c->info.last_eps = NAN; // not measured by an asynchronous solve; hsflow_get_info measures it on demand (c->lastl)
+        if (verdict_only) *verdict_only = 1;
+        return HSFLOW_OK;
+    }
+    if (verdict_only && !gave_up) { // not proven, and the caller decides what follows
+        *verdict_only = 0;
+        c->info.iterations_done = c->pend.iters;
+        c->info.last_eps = NAN;
         return HSFLOW_OK;
     }
     c->lastl.valid = false;
@@ -610,6 +619,8 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
     }
     std::vector<unsigned> heps;
     if ((st = eps_collect(c, iters, heps))) return st;
+    c->sweep_eps.resize((size_t)iters); // (hsflow_solve_probe hands these out)
+    std::memcpy(c->sweep_eps.data(), heps.data(), (size_t)iters * sizeof(float));
     int hit = -1;
     float last = 0.f;
     for (int s2 = 0; s2 < iters; s2++) {
@@ -770,11 +781,14 @@ int prepare_solve(hsflow_ctx *c, const hsflow_params &p, bool async, SolveSetup 
     }
     // PERSIST is the strip kernel as one launch per solve; AUTO takes it where it can run (persist_obstacle)
     const bool persist_asked = p.kernel == HSFLOW_KERNEL_PERSIST;
+    if (use_eps && eps_windowed(c)) small_frame = false; // (the Eps row window is the strip kernel's)
     const int kernel = persist_asked ? HSFLOW_KERNEL_STRIP
                                      : p.kernel != HSFLOW_KERNEL_AUTO ? p.kernel : (small_frame ? HSFLOW_KERNEL_FOLD : HSFLOW_KERNEL_STRIP);
     if (kernel != HSFLOW_KERNEL_SIMPLE && kernel != HSFLOW_KERNEL_FUSED && kernel != HSFLOW_KERNEL_STRIP &&
         kernel != HSFLOW_KERNEL_FOLD)
         return fail(c, HSFLOW_E_ARG, "unknown kernel selector");
+    if (use_eps && eps_windowed(c) && (kernel == HSFLOW_KERNEL_FOLD || kernel == HSFLOW_KERNEL_FUSED))
+        return fail(c, HSFLOW_E_ARG, "EPS termination over a row window (hsflow_set_eps_rows) runs on the strip or the simple kernel");
     const bool multi = kernel != HSFLOW_KERNEL_SIMPLE;
     if (async && use_eps && !(use_iter && p.max_iter > 0 && p.max_iter <= (1 << 16) &&
                               (kernel == HSFLOW_KERNEL_STRIP || kernel == HSFLOW_KERNEL_FOLD) && !c->force_exact))

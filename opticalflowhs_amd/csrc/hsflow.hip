@@ -387,6 +387,54 @@ int hsflow_set_frames_gray8_blur_async(hsflow_ctx *c, int pair, const uint8_t *p
     return HSFLOW_OK;
 }
 
+int hsflow_set_eps_rows(hsflow_ctx *c, int first_row, int rows)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if (rows > 0 && (first_row < 0 || first_row + rows > c->H)) return fail(c, HSFLOW_E_SIZE, "Eps row window outside the frame");
+    if ((st = settle_pending(c))) return st;
+    const int r0 = rows > 0 ? first_row : 0, n = rows > 0 ? rows : 0;
+    if (r0 != c->eps_row0 || n != c->eps_rows) {
+        drop_graphs(c); // captured launches carry the window in their geometry
+        c->lastl.valid = false;
+        c->eps_row0 = r0;
+        c->eps_rows = n;
+    }
+    return HSFLOW_OK;
+}
+
+int hsflow_solve_probe(hsflow_ctx *c, const hsflow_params *pp, float *sweep_eps)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if (!pp || pp->struct_size != sizeof(hsflow_params)) return fail(c, HSFLOW_E_ARG, "params null or struct_size mismatch");
+    if (!sweep_eps) return fail(c, HSFLOW_E_ARG, "sweep_eps is null");
+    if (pp->mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "hsflow_solve_probe: CV mode only");
+    if (pp->max_iter <= 0 || pp->max_iter > (1 << 16)) return fail(c, HSFLOW_E_ARG, "hsflow_solve_probe: max_iter must be 1 .. 65536");
+    hsflow_params q = *pp;
+    q.term_type = HSFLOW_TERM_ITER | HSFLOW_TERM_EPS;
+    q.epsilon = 0.0;  // Eps < 0 never holds: every sweep of the budget runs
+    q.profile = 0;
+    if (q.kernel == HSFLOW_KERNEL_PERSIST) q.kernel = HSFLOW_KERNEL_STRIP;
+    c->force_exact = true; // the per-sweep pass, not the witness pass
+    st = solve_impl(c, &q, false);
+    c->force_exact = false;
+    if (st) return st;
+    if ((int)c->sweep_eps.size() != pp->max_iter) return fail(c, HSFLOW_E_STATE, "hsflow_solve_probe: the per-sweep pass did not run");
+    std::memcpy(sweep_eps, c->sweep_eps.data(), (size_t)pp->max_iter * sizeof(float));
+    return HSFLOW_OK;
+}
+
+int hsflow_take_verdict(hsflow_ctx *c, int *proven)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if (!proven) return fail(c, HSFLOW_E_ARG, "proven is null");
+    if (!c->pend.active) return fail(c, HSFLOW_E_STATE, "no asynchronous ITER|EPS solve is waiting for its early-stop check");
+    *proven = 0;
+    return settle_pending(c, proven);
+}
+
 int hsflow_solve(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, false); }
 int hsflow_solve_async(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, true); }
 

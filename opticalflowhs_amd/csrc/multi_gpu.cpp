@@ -243,6 +243,9 @@ struct Slab {
     // are created on the neighbour's device (an event can only be recorded on a stream of the device it was created on)
     hipEvent_t took_up = nullptr, took_dn = nullptr;
     bool took_up_valid = false, took_dn_valid = false;
+    // ITER|EPS: copies of the slab's flow (all local rows, 2 planes): at the start of the solve (use_previous) and at the
+    // start of the chunk being measured -- allocated when first needed
+    float *start_uv = nullptr, *chunk_uv = nullptr;
 };
 
 } // namespace
@@ -251,7 +254,10 @@ struct hsflow_slab {
     int W = 0, H = 0, halo = 0;
     std::vector<Slab> slabs;
     bool frames_set = false;
+    bool solved = false;      // a solve has run on these frames: the halos hold what its last chunk left there (stale)
     int exchanges = 0;
+    int iterations_done = 0;  // sweeps of the last solve (fewer than the budget when the early stop fired)
+    int eps_measured = 0;     // 1 if the last ITER|EPS solve had to measure Eps sweep by sweep (no slab's witness held)
     std::string err;
 };
 
@@ -311,6 +317,7 @@ int hsflow_slab_destroy(hsflow_slab *s)
         hipSetDevice(sl.device);
         hsflow_destroy(sl.ctx);
         hipFree(sl.send_up); hipFree(sl.send_dn); hipFree(sl.recv_up); hipFree(sl.recv_dn);
+        hipFree(sl.start_uv); hipFree(sl.chunk_uv);
         for (hipEvent_t e : {sl.sent_up, sl.sent_dn, sl.took_up, sl.took_dn})
             if (e) hipEventDestroy(e);
         if (sl.stream) hipStreamDestroy(sl.stream);
@@ -348,6 +355,8 @@ int hsflow_slab_create(hsflow_slab **out, const int *devices, int nslab, int wid
         int st = hsflow_create(&sl.ctx, sl.device, width, sl.local_h, 1, sl.stream, 0);
         if (st) { s->err = std::string("hsflow_create: ") + hsflow_last_error(nullptr); return bail(st); }
         if ((st = hsflow_set_row_origin(sl.ctx, sl.row0))) { s->err = std::string("hsflow_set_row_origin: ") + hsflow_last_error(sl.ctx); return bail(st); }
+        // Eps of the frame = the maximum over the slabs of the Eps of their OWNED rows (the halo rows repeat a neighbour's)
+        if ((st = hsflow_set_eps_rows(sl.ctx, sl.top, sl.hi - sl.lo))) { s->err = std::string("hsflow_set_eps_rows: ") + hsflow_last_error(sl.ctx); return bail(st); }
         const size_t bytes = (size_t)2 * halo * width * sizeof(float);
         if (k > 0) { SL_TRY(hipMalloc((void **)&sl.send_up, bytes)); SL_TRY(hipMalloc((void **)&sl.recv_up, bytes)); }
         if (k + 1 < nslab) { SL_TRY(hipMalloc((void **)&sl.send_dn, bytes)); SL_TRY(hipMalloc((void **)&sl.recv_dn, bytes)); }
@@ -378,6 +387,16 @@ int hsflow_slab_create(hsflow_slab **out, const int *devices, int nslab, int wid
     return HSFLOW_OK;
 }
 
+int hsflow_slab_create_overlapped(hsflow_slab **out, const int *devices, int ndev, int width, int height, int halo)
+{
+    if (!out) return sfail(nullptr, HSFLOW_E_ARG, "out is null");
+    *out = nullptr;
+    if (!devices || ndev < 1 || ndev > 32) return sfail(nullptr, HSFLOW_E_ARG, "devices null or device count out of range (1..32)");
+    std::vector<int> twice;
+    for (int k = 0; k < ndev; k++) { twice.push_back(devices[k]); twice.push_back(devices[k]); }
+    return hsflow_slab_create(out, twice.data(), 2 * ndev, width, height, halo);
+}
+
 int hsflow_slab_count(hsflow_slab *s) { return s ? (int)s->slabs.size() : 0; }
 
 int hsflow_slab_rows(hsflow_slab *s, int k, int *lo, int *hi)
@@ -398,50 +417,181 @@ int hsflow_slab_set_frames_u8(hsflow_slab *s, const uint8_t *prev, size_t ps, co
         SL_CTX(s, sl, hsflow_set_frames_u8(sl.ctx, 0, prev + (size_t)sl.row0 * ps, ps, curr + (size_t)sl.row0 * cs, cs));
     }
     s->frames_set = true;
+    s->solved = false;
     return HSFLOW_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// Neighbouring slabs swap `halo` rows of u, v (enqueue only; ordered by events).
+int exchange_all(hsflow_slab *s)
+{
+    const int n = (int)s->slabs.size();
+    for (int k = 0; k + 1 < n; k++) {
+        Slab &A = s->slabs[(size_t)k], &B = s->slabs[(size_t)k + 1];
+        // A's last owned rows -> B's top halo [0, halo);  B's first owned rows -> A's bottom halo
+        int st = move_rows(s, A, A.top + (A.hi - A.lo) - s->halo, A.send_dn, A.sent_dn, A.took_dn, A.took_dn_valid, B, 0, B.recv_up);
+        if (st) return st;
+        st = move_rows(s, B, B.top, B.send_up, B.sent_up, B.took_up, B.took_up_valid, A, A.top + (A.hi - A.lo), A.recv_dn);
+        if (st) return st;
+    }
+    s->exchanges++;
+    return HSFLOW_OK;
+}
+
+// `sweeps` sweeps on every slab, enqueued (ITER) -- term_type ITER|EPS: witness launches, the checks stay owed.
+int chunk_async(hsflow_slab *s, const hsflow_params &pp, int sweeps, bool from_zero, bool with_deriv, int term_type)
+{
+    hsflow_params q = pp;
+    q.max_iter = sweeps;
+    q.term_type = term_type;
+    q.use_previous = from_zero ? 0 : 1;
+    q.reuse_derivatives = with_deriv ? 0 : 1;
+    q.profile = 0;
+    for (Slab &sl : s->slabs) {
+        SL_HIP(s, hipSetDevice(sl.device));
+        SL_CTX(s, sl, hsflow_solve_async(sl.ctx, &q));
+    }
+    return HSFLOW_OK;
+}
+
+// The slabs' flow (all local rows, halos included) to / from a backup of its own.
+int copy_flows(hsflow_slab *s, float *Slab::*buf, bool save)
+{
+    const size_t rowb = (size_t)s->W * sizeof(float);
+    for (Slab &sl : s->slabs) {
+        SL_HIP(s, hipSetDevice(sl.device));
+        const size_t plane = (size_t)sl.local_h * s->W;
+        if (!(sl.*buf)) SL_HIP(s, hipMalloc((void **)&(sl.*buf), 2 * plane * sizeof(float)));
+        float *b = sl.*buf;
+        if (save) SL_CTX(s, sl, hsflow_get_flow_device(sl.ctx, 0, 0, sl.local_h, b, rowb, b + plane, rowb));
+        else SL_CTX(s, sl, hsflow_set_flow_device(sl.ctx, 0, 0, sl.local_h, b, rowb, b + plane, rowb));
+    }
+    return HSFLOW_OK;
+}
+
+// `done` sweeps from the start of the solve, in the chunks the solve itself used (the replay of a deterministic run).
+int replay(hsflow_slab *s, const hsflow_params &pp, int done)
+{
+    if (pp.use_previous) { const int st = copy_flows(s, &Slab::start_uv, false); if (st) return st; }
+    int at = 0;
+    while (at < done) {
+        const int chunk = std::min(s->halo, done - at);
+        int st = chunk_async(s, pp, chunk, at == 0 && !pp.use_previous, false, HSFLOW_TERM_ITER);
+        if (st) return st;
+        at += chunk;
+        if ((st = exchange_all(s))) return st; // (every replayed chunk was followed by one: the solve went on after it)
+    }
+    return HSFLOW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// Termination as the reference calls the solver (OpticalFlowOpenCV.cpp:29,94: ITER|EPS): the frame's Eps of a sweep is
+// the maximum over the slabs of the Eps of their owned rows, so
+//   * a chunk in which ANY slab's witness proves "my Eps stayed >= epsilon" cannot contain the stop (fast path: witness
+//     launches on every slab, one look at the verdicts per chunk);
+//   * when no slab can vouch for a chunk, the solve is replayed to that chunk's start (it is deterministic) and from
+//     there on every chunk is measured: each slab reports the Eps of every sweep (hsflow_solve_probe), the host takes
+//     the maximum over the slabs and finds the first sweep below epsilon; the chunk is then repeated up to that sweep
+//     from a copy of its starting flow -- the stopping sweep of the one-context solve, bit for bit
+//     (cv210.dll@0x1012f10b-0x1012f14a).
 int hsflow_slab_solve(hsflow_slab *s, const hsflow_params *pp)
 {
     if (!s) return HSFLOW_E_ARG;
     if (!pp || pp->struct_size != sizeof(hsflow_params)) return sfail(s, HSFLOW_E_ARG, "params null or struct_size mismatch");
     if (!s->frames_set) return sfail(s, HSFLOW_E_STATE, "frames were not set");
-    if (pp->term_type != HSFLOW_TERM_ITER || pp->max_iter <= 0)
-        return sfail(s, HSFLOW_E_ARG, "row slabs take ITER termination with max_iter > 0 (EPS would need a reduction over the slabs per sweep)");
-    if (pp->use_previous) return sfail(s, HSFLOW_E_ARG, "row slabs start from zero flow");
-    const int n = (int)s->slabs.size();
-    int done = 0;
+    if (pp->mode != HSFLOW_MODE_CV) return sfail(s, HSFLOW_E_ARG, "row slabs run the CV discretisation");
+    const bool use_eps = (pp->term_type & HSFLOW_TERM_EPS) != 0;
+    if (!(pp->term_type & HSFLOW_TERM_ITER) || pp->max_iter <= 0)
+        return sfail(s, HSFLOW_E_ARG, "row slabs need a sweep budget: ITER or ITER|EPS with max_iter > 0");
+    const int n = (int)s->slabs.size(), budget = pp->max_iter;
     s->exchanges = 0;
-    while (done < pp->max_iter) {
-        const int chunk = n > 1 ? std::min(s->halo, pp->max_iter - done) : pp->max_iter;
-        hsflow_params q = *pp;
-        q.max_iter = chunk;
-        q.use_previous = done > 0;
-        q.reuse_derivatives = done > 0; // derivatives are computed by the first chunk only
-        q.profile = 0;
-        for (Slab &sl : s->slabs) {
-            SL_HIP(s, hipSetDevice(sl.device));
-            SL_CTX(s, sl, hsflow_solve_async(sl.ctx, &q));
+    s->eps_measured = 0;
+    s->iterations_done = 0;
+    int st = HSFLOW_OK;
+    if (n == 1) { // one slab is the whole frame: the context's own solve, its own stop rule
+        Slab &sl = s->slabs[0];
+        SL_HIP(s, hipSetDevice(sl.device));
+        SL_CTX(s, sl, hsflow_solve(sl.ctx, pp));
+        hsflow_info info;
+        info.struct_size = sizeof(info);
+        SL_CTX(s, sl, hsflow_get_info_ex(sl.ctx, &info, 0));
+        s->iterations_done = info.iterations_done;
+        s->eps_measured = info.eps_rerun;
+        s->solved = true;
+        return HSFLOW_OK;
+    }
+    if (pp->use_previous && s->solved && (st = exchange_all(s))) return st; // the halos the last solve left are stale
+    if (pp->use_previous && use_eps && (st = copy_flows(s, &Slab::start_uv, true))) return st;
+    int done = 0;
+    bool measure = false; // every chunk from here on is measured sweep by sweep
+    std::vector<float> eps_s, eps_max;
+    while (done < budget) {
+        const int chunk = std::min(s->halo, budget - done);
+        const bool first = done == 0;
+        const bool from_zero = first && !pp->use_previous;
+        if (!use_eps) {
+            if ((st = chunk_async(s, *pp, chunk, from_zero, first, HSFLOW_TERM_ITER))) return st;
+        } else if (!measure) {
+            if ((st = chunk_async(s, *pp, chunk, from_zero, first, HSFLOW_TERM_ITER | HSFLOW_TERM_EPS))) return st;
+            bool vouched = false;
+            for (Slab &sl : s->slabs) {
+                SL_HIP(s, hipSetDevice(sl.device));
+                int proven = 0;
+                SL_CTX(s, sl, hsflow_take_verdict(sl.ctx, &proven));
+                vouched = vouched || proven != 0;
+            }
+            if (!vouched) { // back to this chunk's start, then measure
+                measure = true;
+                s->eps_measured = 1;
+                if ((st = replay(s, *pp, done))) return st;
+                continue;
+            }
+        } else {
+            if ((st = copy_flows(s, &Slab::chunk_uv, true))) return st;
+            hsflow_params q = *pp;
+            q.max_iter = chunk;
+            q.use_previous = from_zero ? 0 : 1;
+            q.reuse_derivatives = first ? 0 : 1;
+            q.use_graph = 0;
+            eps_s.assign((size_t)chunk, 0.f);
+            eps_max.assign((size_t)chunk, 0.f);
+            for (Slab &sl : s->slabs) {
+                SL_HIP(s, hipSetDevice(sl.device));
+                SL_CTX(s, sl, hsflow_solve_probe(sl.ctx, &q, eps_s.data()));
+                for (int k = 0; k < chunk; k++) eps_max[(size_t)k] = std::max(eps_max[(size_t)k], eps_s[(size_t)k]);
+            }
+            int hit = -1;
+            for (int k = 0; k < chunk && hit < 0; k++)
+                if ((double)eps_max[(size_t)k] < pp->epsilon) hit = k;
+            if (hit >= 0) { // the solve ends after sweep hit + 1 of this chunk
+                if (hit + 1 < chunk) {
+                    if ((st = copy_flows(s, &Slab::chunk_uv, false))) return st;
+                    if ((st = chunk_async(s, *pp, hit + 1, from_zero, false, HSFLOW_TERM_ITER))) return st;
+                }
+                done += hit + 1;
+                break;
+            }
         }
         done += chunk;
-        if (done < pp->max_iter) { // stale rows: closer than `chunk` to a slab's artificial edge -- refresh the halos
-            for (int k = 0; k + 1 < n; k++) {
-                Slab &A = s->slabs[(size_t)k], &B = s->slabs[(size_t)k + 1];
-                // A's last owned rows -> B's top halo [0, halo);  B's first owned rows -> A's bottom halo
-                int st = move_rows(s, A, A.top + (A.hi - A.lo) - s->halo, A.send_dn, A.sent_dn, A.took_dn, A.took_dn_valid, B, 0, B.recv_up);
-                if (st) return st;
-                st = move_rows(s, B, B.top, B.send_up, B.sent_up, B.took_up, B.took_up_valid, A, A.top + (A.hi - A.lo), A.recv_dn);
-                if (st) return st;
-            }
-            s->exchanges++;
-        }
+        if (done < budget && (st = exchange_all(s))) return st; // stale rows: closer than `chunk` to a slab's artificial edge
     }
     for (Slab &sl : s->slabs) {
         SL_HIP(s, hipSetDevice(sl.device));
         SL_CTX(s, sl, hsflow_synchronize(sl.ctx));
     }
+    s->iterations_done = done;
+    s->solved = true;
     return HSFLOW_OK;
 }
+
+int hsflow_slab_iterations_done(hsflow_slab *s) { return s ? s->iterations_done : 0; }
+int hsflow_slab_eps_measured(hsflow_slab *s) { return s ? s->eps_measured : 0; }
 
 int hsflow_slab_exchanges(hsflow_slab *s) { return s ? s->exchanges : 0; }
 

@@ -80,12 +80,14 @@ class MultiPairs(object):
 class SlabFrame(object):
     """One width x height frame in len(devices) row slabs, slab k on devices[k]."""
 
-    def __init__(self, width, height, devices=(0,), halo=16):
+    def __init__(self, width, height, devices=(0,), halo=16, overlapped=False):
+        """overlapped: two sub-slabs per listed device (one's peer copies run under the other's sweeps)."""
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         self.width, self.height = int(width), int(height)
         arr, n = _devs(devices)
-        st = self._lib.hsflow_slab_create(ctypes.byref(self._h), arr, n, self.width, self.height, int(halo))
+        create = self._lib.hsflow_slab_create_overlapped if overlapped else self._lib.hsflow_slab_create
+        st = create(ctypes.byref(self._h), arr, n, self.width, self.height, int(halo))
         if st:
             self._h = None
             raise HsflowError(st, (self._lib.hsflow_slab_last_error(None) or b"").decode())
@@ -116,6 +118,14 @@ class SlabFrame(object):
             params = make_params(**kw)
         self._check(self._lib.hsflow_slab_solve(self._h, ctypes.byref(params)))
         return self._lib.hsflow_slab_exchanges(self._h)
+
+    def iterations_done(self):
+        """Sweeps of the last solve (fewer than max_iter when the early stop of ITER|EPS fired)."""
+        return self._lib.hsflow_slab_iterations_done(self._h)
+
+    def eps_measured(self):
+        """True if the last ITER|EPS solve had to measure Eps sweep by sweep (no slab's witness vouched for some chunk)."""
+        return bool(self._lib.hsflow_slab_eps_measured(self._h))
 
     def flow(self):
         u = np.empty((self.height, self.width), np.float32)

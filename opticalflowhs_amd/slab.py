@@ -94,13 +94,48 @@ class HSFlowSlabBackend(object):
     def set_frames(self, prev, curr):
         self.ctx.set_frames(prev, curr)
 
-    def sweep(self, n, lam, first):
+    def sweep(self, n, lam, first, from_zero=None, eps=None):
+        """n sweeps.  first: the first chunk of a solve (derivative pass); from_zero: start from zero flow (default: first).
+        eps: run them as ITER|EPS witness launches -- enqueued only, the early-stop check stays owed until `verdict()`."""
+        from_zero = first if from_zero is None else from_zero
         # derivatives are computed by the first chunk only; later chunks continue from the flow
-        kw = dict(lam=lam, max_iter=n, term_type=self.hs.TERM_ITER, use_previous=not first, reuse_derivatives=not first)
-        if self.enqueue_only:
+        kw = dict(lam=lam, max_iter=n, term_type=self.hs.TERM_ITER, use_previous=not from_zero, reuse_derivatives=not first)
+        if eps is not None:
+            kw.update(term_type=self.hs.TERM_ITER | self.hs.TERM_EPS, epsilon=eps)
+            self.ctx.solve_async(**kw)
+        elif self.enqueue_only:
             self.ctx.solve_async(**kw)
         else:
             self.ctx.solve(**kw)
+
+    def set_eps_rows(self, first_row, rows):
+        """Only these local rows count for Eps / the witness: the slab's OWNED rows (hsflow_set_eps_rows)."""
+        self.ctx.set_eps_rows(first_row, rows)
+
+    def verdict(self):
+        """Did the witness launches of the last `sweep(..., eps=...)` prove "Eps stayed >= eps in my rows"?  Nothing is re-run."""
+        return self.ctx.take_verdict()
+
+    def probe(self, n, lam, first, from_zero=None):
+        """n sweeps, the Eps of each (over the rows of set_eps_rows) as an fp32 array; synchronous."""
+        from_zero = first if from_zero is None else from_zero
+        return self.ctx.solve_probe(lam=lam, max_iter=n, use_previous=not from_zero, reuse_derivatives=not first)
+
+    def solve_whole(self, lam, iters, eps, use_previous):
+        """The whole solve on this one context (world size 1): its own stop rule.  Returns (sweeps done, measured?)."""
+        kw = dict(lam=lam, max_iter=iters, use_previous=use_previous)
+        kw.update(dict(term_type=self.hs.TERM_ITER) if eps is None else dict(term_type=self.hs.TERM_ITER | self.hs.TERM_EPS, epsilon=eps))
+        i = self.ctx.solve(**kw)
+        return i["iterations_done"], bool(i["eps_rerun"])
+
+    def save(self):
+        """A copy of the slab's flow, halos included (device tensors)."""
+        u, v = self.new_rows(self.height)
+        self.get_rows(0, u, v)
+        return u, v
+
+    def restore(self, saved):
+        self.put_rows(0, saved[0], saved[1])
 
     def new_rows(self, nrows):
         t = self.torch
@@ -143,8 +178,13 @@ class SlabSolver(object):
         self.row0 = self.lo - self.top                    # first frame row held locally
         self.local_height = (self.hi + self.bot) - self.row0
         self.backend = _make(make_backend, width, self.local_height, self.row0)
+        if hasattr(self.backend, "set_eps_rows"):  # Eps of the frame = the maximum over the ranks of the Eps of their OWNED rows
+            self.backend.set_eps_rows(self.top, self.hi - self.lo)
         self.stage_on_host = stage_on_host
         self._bufs = None
+        self._solved = False
+        self.iterations_done = 0
+        self.eps_measured = False
 
     def local_frame_rows(self):
         """Frame rows [row0, row1) this rank must upload (owned rows + halos)."""
@@ -154,6 +194,16 @@ class SlabSolver(object):
         if prev_local.shape != (self.local_height, self.width):
             raise ValueError("local frames must have shape (%d, %d)" % (self.local_height, self.width))
         self.backend.set_frames(prev_local, curr_local)
+        self._solved = False
+
+    def _all_max(self, values):
+        """Element-wise maximum over the ranks of a small fp32 vector (the one collective of the EPS path)."""
+        import torch
+        d = self.dist
+        dev = "cuda" if d.get_backend() == "nccl" else "cpu"
+        t = torch.as_tensor(np.asarray(values, dtype=np.float32), device=dev)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        return t.cpu().numpy()
 
     def _exchange(self):
         """Swap `halo` rows of u, v with the neighbouring ranks (2 sends + 2 recvs per neighbour)."""
@@ -200,15 +250,66 @@ class SlabSolver(object):
         if dn < self.world:
             b.put_rows(self.top + (self.hi - self.lo), *self._bufs["recv_dn"])  # rows [hi, hi+halo)
 
-    def solve(self, lam, iters):
-        """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchanges."""
+    def solve(self, lam, iters, eps=None, use_previous=False):
+        """`iters` Jacobi sweeps on the whole frame, from zero flow or (use_previous) from the flow of the last solve;
+        returns the number of halo exchanges.  eps: ITER|EPS, the reference's own criteria (OpticalFlowOpenCV.cpp:29) --
+        the frame's Eps is the maximum over the ranks of the Eps of their owned rows (cv210.dll@0x1012ed2f-0x1012eda5), so
+          * a chunk that ANY rank's witness vouches for (all_reduce MAX of the verdicts) holds no stop;
+          * when none does, every rank replays the solve to that chunk's start (it is deterministic) and from there on
+            each chunk is measured: per-sweep Eps per rank, all_reduce MAX, first sweep below eps; the chunk is then
+            repeated up to that sweep from a copy of its starting flow.
+        `iterations_done` / `eps_measured` afterwards.  Bit-identical to the one-context solve, stopping sweep included."""
+        b = self.backend
+        self.eps_measured = False
+        if self.world == 1:
+            self.iterations_done, self.eps_measured = b.solve_whole(lam, iters, eps, use_previous) if eps is not None or use_previous else (None, False)
+            if self.iterations_done is None:
+                b.sweep(iters, lam, first=True)
+                self.iterations_done = iters
+            self._solved = True
+            return 0
         n_ex = 0
-        plan = chunks(iters, self.halo) if self.world > 1 else [iters]
-        for i, n in enumerate(plan):
-            self.backend.sweep(n, lam, first=(i == 0))
-            if self.world > 1 and i + 1 < len(plan):
+        if use_previous and self._solved:   # the halos the last solve left are stale
+            self._exchange()
+        start = b.save() if (use_previous and eps is not None) else None
+        plan = chunks(iters, self.halo)
+
+        def run(i, n, witness):
+            b.sweep(n, lam, first=(i == 0), from_zero=(i == 0 and not use_previous), eps=eps if witness else None)
+
+        done, i, measure = 0, 0, False
+        while i < len(plan):
+            n = plan[i]
+            if eps is None:
+                run(i, n, False)
+            elif not measure:
+                run(i, n, True)
+                if self._all_max([1.0 if b.verdict() else 0.0])[0] < 0.5:   # nobody vouches for this chunk
+                    measure = self.eps_measured = True
+                    if start is not None:
+                        b.restore(start)
+                    for j in range(i):                                        # replay to its start
+                        run(j, plan[j], False)
+                        self._exchange()
+                    continue
+            else:
+                saved = b.save()
+                e = self._all_max(b.probe(n, lam, first=(i == 0), from_zero=(i == 0 and not use_previous)))
+                hit = np.nonzero(e.astype(np.float64) < eps)[0]
+                if len(hit):
+                    k = int(hit[0]) + 1
+                    if k < n:
+                        b.restore(saved)
+                        b.sweep(k, lam, first=False, from_zero=(i == 0 and not use_previous))
+                    done += k
+                    break
+            done += n
+            i += 1
+            if i < len(plan):
                 self._exchange()
                 n_ex += 1
+        self.iterations_done = done
+        self._solved = True
         return n_ex
 
     def owned_flow(self):
@@ -318,8 +419,11 @@ class OverlappedSlabSolver(object):
         with bb.activate():
             bb.wait_event(ea2)
 
-    def solve(self, lam, iters):
-        """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchange rounds."""
+    def solve(self, lam, iters, eps=None, use_previous=False):
+        """`iters` Jacobi sweeps from zero flow on the whole frame; returns the number of exchange rounds.
+        (ITER from zero only: ITER|EPS and warm starts are SlabSolver's.)"""
+        if eps is not None or use_previous:
+            raise NotImplementedError("OverlappedSlabSolver runs ITER from zero flow; use SlabSolver for ITER|EPS / use_previous")
         A, B = self.subs
         plan = chunks(iters, self.halo)
         n_ex = 0

@@ -166,6 +166,23 @@ class HSFlow(object):
         p = params if params is not None else self.make_params(**kw)
         self._check(self._lib.hsflow_solve_async(self._h, ctypes.byref(p)))
 
+    def set_eps_rows(self, first_row, rows):
+        """Only the changes of rows [first_row, first_row + rows) count for Eps / the witness (rows <= 0: the whole frame)."""
+        self._check(self._lib.hsflow_set_eps_rows(self._h, int(first_row), int(rows)))
+
+    def solve_probe(self, params=None, **kw):
+        """Exactly max_iter sweeps, nothing stops them; returns the Eps of every sweep (fp32 array)."""
+        p = params if params is not None else self.make_params(**kw)
+        out = np.empty(int(p.max_iter), np.float32)
+        self._check(self._lib.hsflow_solve_probe(self._h, ctypes.byref(p), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out
+
+    def take_verdict(self):
+        """The early-stop check an asynchronous ITER|EPS solve owes, without acting on it: True = "no early stop" proven."""
+        v = ctypes.c_int(0)
+        self._check(self._lib.hsflow_take_verdict(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     def synchronize(self):
         self._check(self._lib.hsflow_synchronize(self._h))
 

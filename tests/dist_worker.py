@@ -23,13 +23,54 @@ class OracleSlabBackend(object):
         self.width, self.height = width, height
         self.u = np.zeros((height, width), np.float32)
         self.v = np.zeros((height, width), np.float32)
+        self.win = (0, height)
+        self._proven = False
 
     def set_frames(self, prev, curr):
         self.prev, self.curr = np.ascontiguousarray(prev), np.ascontiguousarray(curr)
 
-    def sweep(self, n, lam, first):
-        self.u, self.v = hs_oracle.calc_optical_flow_hs(self.prev, self.curr, lam, n, term_type=hs_oracle.TERMCRIT_ITER,
-                                                       use_previous=not first, velx=self.u, vely=self.v)
+    def _one(self, lam, from_zero):
+        """One sweep; returns its Eps over the rows of set_eps_rows (fp32 differences, like the original's)."""
+        u, v = hs_oracle.calc_optical_flow_hs(self.prev, self.curr, lam, 1, term_type=hs_oracle.TERMCRIT_ITER,
+                                              use_previous=not from_zero, velx=self.u, vely=self.v)
+        u0 = np.zeros_like(u) if from_zero else self.u
+        v0 = np.zeros_like(v) if from_zero else self.v
+        a, b = self.win
+        e = max(float(np.max(np.abs(u0[a:b] - u[a:b]))), float(np.max(np.abs(v0[a:b] - v[a:b]))))
+        self.u, self.v = u, v
+        return np.float32(e)
+
+    def sweep(self, n, lam, first, from_zero=None, eps=None):
+        from_zero = first if from_zero is None else from_zero
+        if eps is None:
+            self.u, self.v = hs_oracle.calc_optical_flow_hs(self.prev, self.curr, lam, n, term_type=hs_oracle.TERMCRIT_ITER,
+                                                           use_previous=not from_zero, velx=self.u, vely=self.v)
+            return
+        # "witness": here simply the truth -- did Eps stay >= eps in every sweep of the chunk, over my rows?
+        e = [self._one(lam, from_zero and k == 0) for k in range(n)]
+        self._proven = all(float(x) >= eps for x in e)
+
+    def set_eps_rows(self, first_row, rows):
+        self.win = (first_row, first_row + rows)
+
+    def verdict(self):
+        return self._proven
+
+    def probe(self, n, lam, first, from_zero=None):
+        from_zero = first if from_zero is None else from_zero
+        return np.array([self._one(lam, from_zero and k == 0) for k in range(n)], np.float32)
+
+    def solve_whole(self, lam, iters, eps, use_previous):
+        tt = hs_oracle.TERMCRIT_ITER if eps is None else hs_oracle.TERMCRIT_ITER | hs_oracle.TERMCRIT_EPS
+        self.u, self.v, it, _ = hs_oracle.calc_optical_flow_hs(self.prev, self.curr, lam, iters, epsilon=eps if eps is not None else 1e-6, term_type=tt,
+                                                              use_previous=use_previous, velx=self.u, vely=self.v, return_info=True)
+        return it, False
+
+    def save(self):
+        return self.u.copy(), self.v.copy()
+
+    def restore(self, saved):
+        self.u, self.v = saved[0].copy(), saved[1].copy()
 
     def new_rows(self, nrows):
         return torch.empty((nrows, self.width), dtype=torch.float32), torch.empty((nrows, self.width), dtype=torch.float32)
@@ -71,10 +112,21 @@ def main():
     r0, r1 = s.local_frame_rows()
     A, B = synth.translating_pair(W, H, seed=3, row0=r0, rows=r1 - r0)  # each rank makes only its rows
     s.set_frames(A, B)
-    n_ex = s.solve(0.7, iters)
-    u, v = s.owned_flow()
+    extra = {}
+    if len(sys.argv) > 6 and sys.argv[6].startswith("eps="):
+        # ITER|EPS over the slabs, then a warm start: "eps=<epsilon>,<lambda>"
+        eps, lam = (float(x) for x in sys.argv[6][4:].split(","))
+        n_ex = s.solve(lam, iters, eps=eps)
+        extra = dict(done=s.iterations_done, measured=s.eps_measured)
+        u, v = s.owned_flow()
+        s.solve(lam, 7, eps=eps, use_previous=True)
+        uw, vw = s.owned_flow()
+        extra.update(uw=uw, vw=vw, done_warm=s.iterations_done)
+    else:
+        n_ex = s.solve(0.7, iters)
+        u, v = s.owned_flow()
     np.savez(os.path.join(out, "rank%d.npz" % rank), u=u, v=v, lo=s.lo, hi=s.hi, n_ex=n_ex,
-             pairs=np.array(slab.shard_pairs(11, world, rank)))
+             pairs=np.array(slab.shard_pairs(11, world, rank)), **extra)
     dist.barrier()
     dist.destroy_process_group()
 

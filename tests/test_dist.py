@@ -58,3 +58,28 @@ def test_slab_exchange_matches_single_domain(tmp_path, oracle, world, halo, iter
         pairs += list(d["pairs"])
     assert np.array_equal(u, uo) and np.array_equal(v, vo)
     assert sorted(pairs) == list(range(11))
+
+
+@pytest.mark.parametrize("world,halo,iters,eps,lam", [(2, 4, 30, 1e-6, 0.7), (2, 5, 60, 2e-2, 0.7), (3, 4, 60, 5e-3, 0.7), (2, 6, 40, 0.3, 0.7), (1, 4, 60, 2e-2, 0.7)])
+def test_slab_iter_eps_matches_single_domain(tmp_path, oracle, world, halo, iters, eps, lam):
+    """ITER|EPS over the ranks (gloo, all_reduce MAX of the witness verdicts and of the per-sweep Eps): the stopping sweep
+    and the flow of the single-domain oracle solve, and of a warm start after it, bit for bit."""
+    W, H = 96, 61
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + world * 10 + halo),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(W), str(H), str(halo), str(iters), str(tmp_path), "eps=%r,%r" % (eps, lam)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    A, B = synth.translating_pair(W, H, seed=3)
+    uo, vo, k, _ = oracle.calc_optical_flow_hs(A, B, lam, iters, epsilon=eps, term_type=3, return_info=True)
+    uw, vw, kw, _ = oracle.calc_optical_flow_hs(A, B, lam, 7, epsilon=eps, term_type=3, use_previous=True, velx=uo, vely=vo, return_info=True)
+    u, v, u2, v2 = (np.zeros_like(uo) for _ in range(4))
+    for rank in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        lo, hi = int(d["lo"]), int(d["hi"])
+        u[lo:hi], v[lo:hi], u2[lo:hi], v2[lo:hi] = d["u"], d["v"], d["uw"], d["vw"]
+        assert int(d["done"]) == k and int(d["done_warm"]) == kw, (rank, int(d["done"]), k, int(d["done_warm"]), kw)
+        assert bool(d["measured"]) == (k < iters and world > 1) or world == 1 or k == iters
+    assert np.array_equal(u, uo) and np.array_equal(v, vo)
+    assert np.array_equal(u2, uw) and np.array_equal(v2, vw)

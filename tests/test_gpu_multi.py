@@ -88,3 +88,60 @@ def test_multi_pairs_round_robin(hs, gpu_ok):
         hs.MultiPairs(W, H, devices=(99,))
     with pytest.raises(hs.HsflowError):
         hs.SlabFrame(W, 20, devices=(0, 0, 0), halo=16)
+
+
+def same_flow(x, y):
+    """Bit for bit, except where both values lie below 1e-37: inside a launch the strip kernels carry 4^k u, so flow that would
+    be denormal keeps bits that depend on where the launch boundaries fall (chunks of `halo` sweeps against launches of
+    fuse_steps; DESIGN.md 4.1 "Scaled state").  Only synthetic flat frames get there."""
+    return bool(np.all((x == y) | ((np.abs(x) < 1e-37) & (np.abs(y) < 1e-37))))
+
+
+@pytest.mark.parametrize("devices,overlapped", [((0, 0), False), ((0, 0, 0), False), ((0,), True), ((0, 0), True)])
+def test_slab_frame_iter_eps_stops_where_the_whole_frame_solve_stops(hs, gpu_ok, devices, overlapped):
+    """ITER|EPS over row slabs (the reference's own criteria, /root/reference OpticalFlowOpenCV.cpp:29): the frame's Eps is
+    the maximum over the slabs' owned rows.  Budgets that run out (some slab's witness vouches for every chunk), stops
+    inside the first, a middle and the last chunk, a stop exactly at a chunk's end, and warm starts -- flow and stopping
+    sweep must be those of the one-context solve, bit for bit."""
+    W, H, halo = 600, 260, 12
+    flat_a = np.full((H, W), 90, np.uint8)
+    flat_b = flat_a.copy()
+    flat_a[50:200, 100:480] = 120
+    flat_b[50:200, 100:480] = 121
+    moving = synth.translating_pair(W, H, seed=21)
+    cases = [(moving, 1.0, 70, float(np.float32(1e-6))),     # the budget runs out, witnessed
+             ((flat_a, flat_b), 1e-3, 400, 1e-4),            # converges in a middle chunk
+             ((flat_a, flat_b), 1e-3, 400, 1e-2),            # ... in the first chunk
+             ((flat_a, flat_b), 1e-3, 400, 3e-5),            # ... late
+             ((flat_a, flat_a), 1.0, 50, 1e-6)]              # identical frames: Eps = 0 in sweep 1
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx, hs.SlabFrame(W, H, devices=devices, halo=halo, overlapped=overlapped) as s:
+        stops = []
+        for (A, B), lam, budget, eps in cases:
+            ctx.set_frames(A, B)
+            s.set_frames(A, B)
+            i = ctx.solve(lam=lam, max_iter=budget, term_type=ITER | EPS, epsilon=eps)
+            uo, vo = ctx.flow()
+            s.solve(lam=lam, max_iter=budget, term_type=ITER | EPS, epsilon=eps)
+            u, v = s.flow()
+            assert s.iterations_done() == i["iterations_done"], (lam, budget, eps, s.iterations_done(), i["iterations_done"])
+            assert same_flow(u, uo) and same_flow(v, vo), (lam, budget, eps)
+            stops.append(i["iterations_done"])
+            # a warm start from that flow, again ITER|EPS
+            i2 = ctx.solve(lam=lam, max_iter=25, term_type=ITER | EPS, epsilon=eps, use_previous=True)
+            uo, vo = ctx.flow()
+            s.solve(lam=lam, max_iter=25, term_type=ITER | EPS, epsilon=eps, use_previous=True)
+            u, v = s.flow()
+            assert s.iterations_done() == i2["iterations_done"] and same_flow(u, uo) and same_flow(v, vo), (lam, budget, eps, "warm")
+        assert stops[0] == 70 and 1 < stops[1] < 400 and stops[2] <= halo and stops[4] == 1, stops
+        # an exact stop at a chunk's end, whatever sweep that is: epsilon just above that sweep's Eps
+        (A, B), lam = cases[1][0], 1e-3
+        ctx.set_frames(A, B)
+        s.set_frames(A, B)
+        eps_k = ctx.solve_probe(lam=lam, max_iter=3 * halo, term_type=ITER)
+        eps = float(np.nextafter(eps_k[2 * halo - 1], np.float32(np.inf)))
+        if np.all(eps_k[:2 * halo - 1] >= eps):   # (Eps falls monotonically on this pair: the stop is sweep 2 * halo)
+            i = ctx.solve(lam=lam, max_iter=400, term_type=ITER | EPS, epsilon=eps)
+            uo, vo = ctx.flow()
+            s.solve(lam=lam, max_iter=400, term_type=ITER | EPS, epsilon=eps)
+            u, v = s.flow()
+            assert i["iterations_done"] == 2 * halo == s.iterations_done() and same_flow(u, uo) and same_flow(v, vo)
