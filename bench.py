@@ -170,6 +170,110 @@ def run_fresh_frames(args, hs, synth, torch, local_rank, W, H, iters, p_ieps, ba
             "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"], "depth": depth}
 
 
+def read_pgm(path):
+    """Binary PGM (P5, maxval 255) -> (H, W) uint8."""
+    with open(path, "rb") as f:
+        data = f.read()
+    tok, pos = [], 0
+    while len(tok) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        tok.append(data[pos:end])
+        pos = end
+    if tok[0] != b"P5" or int(tok[3]) != 255:
+        raise ValueError("not an 8-bit binary PGM")
+    w, h = int(tok[1]), int(tok[2])
+    return np.frombuffer(data, np.uint8, w * h, pos + 1).reshape(h, w).copy()
+
+
+def run_reference_default(args, hs, synth, torch, local_rank, with_cpu):
+    """The workload the reference's authors ran (main.cpp:4-8,16,20): the city pair, 600x480, lambda 0.1, 100 iterations,
+    the CPU route's call -- 3x3 blur of both frames, then cvCalcOpticalFlowHS with ITER|EPS (OpticalFlowOpenCV.cpp:26-30).
+    Frames: the committed gray fixtures of the reference's city_1/2.jpg where present, else a synthetic pair of that size.
+    Four figures: one solve after the other on one context with the blurred frames resident (`latency`); a stream of
+    resident pairs through the pair pipeline (`stream`: the planner's own launch shape, and large tiles picked by hand);
+    end to end from page-locked host memory (gray upload, blur on the device, solve, flow download; `end_to_end`); and the
+    CPU port (blur + oracle, one thread) beside them."""
+    W, H, it, lam = 600, 480, 100, 0.1
+    eps6 = float(np.float32(1e-6))
+    g = [os.path.join(ROOT, "tests", "golden", "city_%d_gray.pgm" % k) for k in (1, 2)]
+    if all(os.path.exists(x) for x in g):
+        A, B = read_pgm(g[0]), read_pgm(g[1])
+        src = "tests/golden/city_{1,2}_gray.pgm (the reference's city pair as gray planes)"
+    else:
+        A, B = synth.translating_pair(W, H, seed=4)
+        src = "synthetic translating texture, seed 4"
+    out = {"what": "600x480, lambda 0.1, 100 iterations, ITER|EPS (eps 1e-6), 3x3 blur first: main.cpp:4-8 / OpticalFlowOpenCV.cpp:26-30", "frames": src,
+           "unit": "ms per pair"}
+    p = hs.make_params(lam=lam, max_iter=it, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=eps6, use_graph=True)
+    p_big = hs.make_params(lam=lam, max_iter=it, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=eps6, use_graph=True, kernel=hs.KERNEL_STRIP,
+                           fuse_steps=20, strip_rows=5, threads=768)
+    n = 300
+    with hs.HSFlow(W, H, 1, device=local_rank, own_stream=True) as ctx:
+        ctx.set_frames_gray_blur(A, B)
+        Ab, Bb = ctx.frames()
+        for _ in range(30):
+            ctx.solve_async(p)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.solve_async(p)
+        ctx.synchronize()
+        info = ctx.info()
+        out["latency"] = {"ms": (time.perf_counter() - t0) / n * 1e3, "kernel": {hs.KERNEL_STRIP: "strip", hs.KERNEL_FOLD: "fold"}.get(info["kernel"]),
+                          "fuse_steps": info["fuse_steps"], "tiles": info["tiles"], "iterations_done": info["iterations_done"],
+                          "what": "the blurred pair resident, one hsflow_solve_async after the other on one context"}
+    dA, dB = torch.from_numpy(Ab).to("cuda:%d" % local_rank), torch.from_numpy(Bb).to("cuda:%d" % local_rank)
+    torch.cuda.synchronize()
+    for name, pp_, depth in (("stream", p, 8), ("stream_large_tiles", p_big, 8)):
+        with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
+            def go(k):
+                for _ in range(k):
+                    pl.submit_device(dA, dB, params=pp_)
+                pl.drain()
+            go(4 * depth)
+            t0 = time.perf_counter()
+            go(n)
+            ms = (time.perf_counter() - t0) / n * 1e3
+            i2 = pl.info(pl.submit_device(dA, dB, params=pp_))
+        out[name] = {"ms": ms, "depth": depth, "tiles": i2["tiles"], "fuse_steps": i2["fuse_steps"], "rows": i2["groups_per_thread"], "threads": i2["threads"],
+                     "what": "resident pairs through hsflow_pipeline_submit_device (frame copy, solve, own early-stop check per pair)"}
+    out["stream_large_tiles"]["what"] += "; launch shape picked by hand (strip kernel, 20 sweeps per launch, 5 rows per lane, 768 threads): few large " \
+                                         "tiles per solve, several solves side by side (profiles/r03_pipeline_shapes.txt)"
+    depth = 4
+    with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
+        a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)
+        a[...], b[...] = A, B
+        outs = [(hs.pinned_empty((H, W), np.float32), hs.pinned_empty((H, W), np.float32)) for _ in range(depth + 1)]
+
+        def go2(k):
+            for j in range(k):
+                pl.submit(a, b, outs[j % (depth + 1)][0], outs[j % (depth + 1)][1], params=p, frames="gray_blur")
+            pl.drain()
+        go2(3 * depth)
+        t0 = time.perf_counter()
+        go2(n)
+        out["end_to_end"] = {"ms": (time.perf_counter() - t0) / n * 1e3, "depth": depth,
+                             "what": "page-locked host gray frames in, flow out: upload, 3x3 blur on the device, solve, download (hsflow_pipeline_submit_ex)"}
+    if with_cpu:
+        from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
+        hs_oracle.build()
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 1 or time.perf_counter() - t0 < 2.0:
+            a2, b2 = hs_oracle.box_blur3(A), hs_oracle.box_blur3(B)
+            hs_oracle.calc_optical_flow_hs(a2, b2, lam, it, epsilon=eps6, term_type=hs_oracle.TERMCRIT_ITER | hs_oracle.TERMCRIT_EPS)
+            reps += 1
+        out["cpu_port"] = {"ms": (time.perf_counter() - t0) / reps * 1e3, "cores": 1, "kind": "port", "what": "blur + oracle, one thread, %d run(s)" % reps}
+    return out
+
+
 def run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max):
     """BASELINE config C5: one --c5-size^2 frame (seed 3) in row slabs over the ranks, --c5-iters sweeps in
     chunks of --c5-halo with `halo` rows of u, v swapped between neighbouring ranks after every chunk
@@ -586,6 +690,7 @@ def main():
             out["fresh_frames"] = {"error": str(e)}
     # the reference's own OpenCL discretisation (Kernels.cl, `-cl` route: 8-neighbour mean, alpha^2, IEEE division) on the
     # same frames, beside the headline: a side figure, never `value`
+    pl_ok = loop == "stream"
     if rank == 0 and not args.no_side and args.kernel == "auto":
         try:
             pc = ctx.make_params(mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=iters, term_type=hs.TERM_ITER)
@@ -599,7 +704,21 @@ def main():
             ctx.synchronize()
             cms = (time.perf_counter() - t0) / nc * 1e3
             ic = ctx.info()
+            stream_ms = None
+            if pl_ok:
+                with hs.PairPipeline(W, H, depth=2, device=local_rank) as plc:
+                    pcg = ctx.make_params(mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=iters, term_type=hs.TERM_ITER, use_graph=True)
+
+                    def goc(k):
+                        for j in range(k):
+                            plc.submit_device(dev_pairs[j & 1][0], dev_pairs[j & 1][1], params=pcg)
+                        plc.drain()
+                    goc(10)
+                    t0 = time.perf_counter()
+                    goc(nc)
+                    stream_ms = (time.perf_counter() - t0) / nc * 1e3
             out["classic_mode"] = {"what": "Kernels.cl discretisation (v update restored), alpha 15, ITER, %d sweeps, same frames" % iters,
+                                   "stream_ms_per_step": stream_ms, "stream_what": "a new resident pair every step through the two-slot pair pipeline",
                                    "ms_per_step": cms, "value": px * iters / (cms * 1e-3) / 1e6, "unit": "Mpix*iter/s",
                                    "kernel": {hs.KERNEL_STRIP: "strip", hs.KERNEL_FUSED: "fused", hs.KERNEL_SIMPLE: "simple"}.get(ic["kernel"], str(ic["kernel"])),
                                    "fuse_steps": ic["fuse_steps"], "rows_per_lane_or_groups": ic["groups_per_thread"], "threads": ic["threads"],
@@ -623,6 +742,11 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["c5_slab"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if rank == 0 and world == 1 and not args.no_side and args.kernel == "auto" and (W, H, iters) == (1920, 1080, 100):
+        try:
+            out["reference_default_workload"] = run_reference_default(args, hs, synth, torch, local_rank, with_cpu=not args.skip_cpu)
+        except Exception as e:  # noqa: BLE001 -- a side figure must not cost the headline
+            out["reference_default_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.skip_cpu:
         from oracle import hs_oracle  # cpu_baseline leg only: the oracle timed as the CPU port
         hs_oracle.build()

@@ -708,11 +708,17 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     if (stamps) st2 = __builtin_amdgcn_s_memtime();
 
     if constexpr (!PERSIST) {
+        // (the lane's column is worked out afresh from a copy of the lane number the optimiser cannot see through: kept
+        // alive across the sweep loop it is one of the three registers the loop has no room for -- every spilled register
+        // is 250 KB of scratch written and read per launch, which showed up as HBM writes: profiles/r03_traffic_by_kernel.json)
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int x0s = bx * g.CW - g.HX + 4 * lane_s;
         if (lanecore) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if ((rowcore >> r) & 1u) {
-                    const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0;
+                    const long long off = base + (long long)(y0 + img_row(r)) * g.P + x0s;
                     // (non-temporal and agent-scope write-through stores were tried here: both slower)
                     const float fin = HS_SCALED ? __builtin_ldexpf(1.0f, -2 * g.T) : 1.0f; // back to scale 1 (exact)
                     // P = (p0, p3), Q = (p1, p2)

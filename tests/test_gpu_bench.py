@@ -62,6 +62,12 @@ def test_bench_single_gpu_line(gpu_ok):
     assert rf["traffic_measured_in_run"] is False and (rf["traffic"] is None or rf["traffic"] < rf["hbm_algorithmic"]["bytes_per_launch"])
     assert rf["hbm_algorithmic"]["bytes_per_pixel_sweep"] == 28.0
     assert abs(d["value"] - 1920 * 1080 * 100 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    # the workload the reference's authors ran (600x480 city pair, lambda 0.1, 100 iterations, blur first): latency, stream, end to end, CPU port
+    rd = d["reference_default_workload"]
+    assert "error" not in rd, rd
+    assert rd["latency"]["iterations_done"] == 100 and 0 < rd["stream_large_tiles"]["ms"] and 0 < rd["stream"]["ms"] and 0 < rd["end_to_end"]["ms"]
+    assert rd["latency"]["ms"] < 0.2 and rd["cpu_port"]["cores"] == 1 and rd["cpu_port"]["ms"] > rd["latency"]["ms"]
+    assert 0 < d["classic_mode"]["stream_ms_per_step"] < d["classic_mode"]["ms_per_step"] * 1.05
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mpix*iter/s"
 
