@@ -231,7 +231,7 @@ def run_reference_default(args, hs, synth, torch, local_rank, with_cpu):
                           "what": "the blurred pair resident, one hsflow_solve_async after the other on one context"}
     dA, dB = torch.from_numpy(Ab).to("cuda:%d" % local_rank), torch.from_numpy(Bb).to("cuda:%d" % local_rank)
     torch.cuda.synchronize()
-    for name, pp_, depth in (("stream", p, 8), ("stream_large_tiles", p_big, 8)):
+    for name, pp_, depth in (("stream", p, 8), ("stream_shape_by_hand", p_big, 8)):
         with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
             def go(k):
                 for _ in range(k):
@@ -244,8 +244,8 @@ def run_reference_default(args, hs, synth, torch, local_rank, with_cpu):
             i2 = pl.info(pl.submit_device(dA, dB, params=pp_))
         out[name] = {"ms": ms, "depth": depth, "tiles": i2["tiles"], "fuse_steps": i2["fuse_steps"], "rows": i2["groups_per_thread"], "threads": i2["threads"],
                      "what": "resident pairs through hsflow_pipeline_submit_device (frame copy, solve, own early-stop check per pair)"}
-    out["stream_large_tiles"]["what"] += "; launch shape picked by hand (strip kernel, 20 sweeps per launch, 5 rows per lane, 768 threads): few large " \
-                                         "tiles per solve, several solves side by side (profiles/r03_pipeline_shapes.txt)"
+    out["stream"]["what"] += "; launch shape: the pipeline's own for small frames at depth >= 3 (few large tiles per solve, several solves side by side)"
+    out["stream_shape_by_hand"]["what"] += "; the same shape passed explicitly (strip kernel, 20 sweeps per launch, 5 rows per lane, 768 threads)"
     depth = 4
     with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
         a, b = hs.pinned_empty((H, W), np.uint8), hs.pinned_empty((H, W), np.uint8)

@@ -166,6 +166,13 @@ int hsflow_set_row_origin(hsflow_ctx *ctx, int first_row);
  * Results are bit-identical whatever the shape. */
 int hsflow_set_cu_share(hsflow_ctx *ctx, int compute_units);
 
+/* on != 0: an asynchronous ITER|EPS solve enqueues the reduction of its witness words right behind its last launch (a
+ * small kernel per solve on the context's stream) instead of leaving it to whoever settles the check: settling then costs
+ * the host a wait and a look, no launch and no second round trip.  Pays where the stream is not the bottleneck -- the
+ * slots of a pair pipeline set it: their streams overlap, and for small frames the host's time per pair is what bounds
+ * the stream.  Off by default: back-to-back solves on ONE stream would pay the kernel and its boundary every time. */
+int hsflow_set_async_reduce(hsflow_ctx *ctx, int on);
+
 /* --- building blocks for drivers that run ONE solve over several contexts (row slabs, hsflow_slab_*) ----------- */
 
 /* Only the changes of rows [first_row, first_row + rows) count for Eps and for the witness of ITER|EPS solves (rows <= 0:

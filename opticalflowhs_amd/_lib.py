@@ -52,6 +52,7 @@ PROTOTYPES = {
     "hsflow_destroy": (_i, [_vp]),
     "hsflow_set_row_origin": (_i, [_vp, _i]),
     "hsflow_set_cu_share": (_i, [_vp, _i]),
+    "hsflow_set_async_reduce": (_i, [_vp, _i]),
     "hsflow_set_eps_rows": (_i, [_vp, _i, _i]),
     "hsflow_solve_probe": (_i, [_vp, _pp, ctypes.POINTER(ctypes.c_float)]),
     "hsflow_take_verdict": (_i, [_vp, ctypes.POINTER(_i)]),

@@ -84,6 +84,7 @@ struct hsflow_ctx {
     bool counted = false;        // this context is in g_live_ctx
     int eps_row0 = 0, eps_rows = 0; // hsflow_set_eps_rows: rows whose changes count for Eps (0 rows: the whole frame)
     std::vector<float> sweep_eps;   // Eps of every sweep of the last exact (per-sweep) pass: hsflow_solve_probe hands it out
+    bool async_reduce = false;      // hsflow_set_async_reduce
     int cu_share = 0;            // > 0: the planners count on this many CUs only (hsflow_set_cu_share); 0: the whole chip
     int num_cu = 0;              // compute units of the device (one workgroup of the persistent launch per CU)
     void *dScratch = nullptr;   // staging for colour frames / derivative read-back
@@ -99,6 +100,7 @@ struct hsflow_ctx {
         hsflow_params params;
         int iters = 0, slots = 0, launches = 0, cur0 = 0;
         int stride = 1, n_first = 0, cnt_first = 0, cnt_last = 0; // layout of its witness words (k_eps_reduce's arguments)
+        bool reduced = false;   // the reduction into hEps was enqueued with the solve (async_reduce)
     } pend;
     // what it takes to measure last_eps of an asynchronous ITER|EPS solve on demand (hsflow_get_info): its last
     // launch again, from the input buffer that launch left intact, with the final sweep's Eps measured

@@ -30,9 +30,11 @@ int settle_pending(hsflow_ctx *c, int *verdict_only = nullptr)
     // the witness words of that solve's launches are still per workgroup: an asynchronous solve enqueues no
     // reduction (a stream of solves would pay a kernel and a boundary per solve for words nobody reads); now
     // that somebody wants the verdict, reduce them into the host's buffer and wait
-    c->epsStride = c->pend.stride;
-    int st0 = eps_collect_enqueue(c, c->pend.slots, c->pend.n_first, c->pend.cnt_first, c->pend.cnt_last);
-    if (st0) return st0;
+    if (!c->pend.reduced) { // (hsflow_set_async_reduce: the solve enqueued the reduction itself, right behind its last launch)
+        c->epsStride = c->pend.stride;
+        int st0 = eps_collect_enqueue(c, c->pend.slots, c->pend.n_first, c->pend.cnt_first, c->pend.cnt_last);
+        if (st0) return st0;
+    }
     HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
     const bool gave_up = c->persist_unchecked && persist_error(c); // a persistent launch that timed out proves nothing
@@ -502,17 +504,17 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 fuse = false;
                 launches++;
             }
-            if (async) { // the reduction of the witness words waits until somebody settles the check (settle_pending)
+            if (async && !c->async_reduce) { // the reduction of the witness words waits until somebody settles the check (settle_pending)
                 c->epsPtr = c->dEps;
                 c->epsStride = 1;
                 return HSFLOW_OK;
             }
             return eps_collect_enqueue(c, slots, n_launch - 1, plan_eps_stride(kernel, plan),
-                                       plan_eps_stride(kernel, last_chunk != T ? tailp : plan));
+                                       plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan));
         };
         if (p.use_graph && !p.profile) {
             GraphKey key{p.mode, persist ? HSFLOW_KERNEL_PERSIST : kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
-                         c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0) + (async ? 4 : 0), coeff, c->epsThr};
+                         c->info.groups_per_thread, p.use_previous ? c->cur : 0, p.use_previous * 2 + (do_deriv ? 1 : 0) + (async ? 4 : 0) + (async && c->async_reduce ? 8 : 0), coeff, c->epsThr};
             auto configure = [&]() -> int {
                 if (persist) {
                     hsk::PersistArgs none{};
@@ -564,6 +566,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             c->pend.iters = iters; c->pend.slots = slots; c->pend.launches = launches; c->pend.cur0 = cur0;
             c->pend.stride = stride; c->pend.n_first = n_launch - 1; c->pend.cnt_first = plan_eps_stride(kernel, plan);
             c->pend.cnt_last = plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan);
+            c->pend.reduced = c->async_reduce;
             c->info.iterations_done = iters;
             c->info.jacobi_launches = launches;
             return HSFLOW_OK;

@@ -387,6 +387,15 @@ int hsflow_set_frames_gray8_blur_async(hsflow_ctx *c, int pair, const uint8_t *p
     return HSFLOW_OK;
 }
 
+int hsflow_set_async_reduce(hsflow_ctx *c, int on)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    if ((st = settle_pending(c))) return st;
+    c->async_reduce = on != 0;
+    return HSFLOW_OK;
+}
+
 int hsflow_set_eps_rows(hsflow_ctx *c, int first_row, int rows)
 {
     int st = check_ctx(c, 0);

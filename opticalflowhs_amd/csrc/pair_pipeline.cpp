@@ -26,6 +26,7 @@ struct hsflow_pipeline {
     };
     std::vector<Slot> slots;
     uint64_t next = 0;
+    int width = 0, height = 0;
     std::string err;
 };
 
@@ -43,6 +44,34 @@ int pfail(hsflow_pipeline *pl, int code, const std::string &msg)
 int ctx_fail(hsflow_pipeline *pl, hsflow_ctx *ctx, int code, const char *what)
 {
     return pfail(pl, code, std::string(what) + ": " + hsflow_last_error(ctx));
+}
+
+// The launch shape for a pair whose caller left everything to the planner, when three or more slots share the chip and the
+// frame is small: the planner shapes a solve for its own latency -- a 600x480 frame is cut into 210 tiles of 88x16 so
+// that every CU gets one, at five times the halo arithmetic -- but with the other slots' solves running beside it the
+// chip is full anyway and what counts is the CU-time a solve costs: few large tiles (strip kernel, 20 sweeps per launch,
+// 5 rows per lane; 16 wavefronts, or 12 where that would leave fewer than ~50 tiles).  Measured at depth 8 on MI355X,
+// ms per pair, planner's shape -> this one: 424x240 0.066 -> 0.051, 640x480 0.085 -> 0.053, 800x600 0.093 -> 0.061,
+// 1280x720 0.114 -> 0.075 (depth 3: 0.107 -> 0.066); from 1080p on the planner's shape is already this one
+// (profiles/r03_pipeline_shapes.txt).  Results are bit-identical whatever the shape.  HSFLOW_PIPELINE_AUTO_SHAPE=0: off.
+hsflow_params stream_shape(const hsflow_pipeline *pl, const hsflow_params &in)
+{
+    static const bool off = getenv("HSFLOW_PIPELINE_AUTO_SHAPE") && atoi(getenv("HSFLOW_PIPELINE_AUTO_SHAPE")) == 0;
+    hsflow_params p = in;
+    const long long px = (long long)pl->width * pl->height;
+    if (off || pl->slots.size() < 3 || p.struct_size != sizeof(hsflow_params) || p.mode != HSFLOW_MODE_CV || p.kernel != HSFLOW_KERNEL_AUTO ||
+        p.fuse_steps || p.strip_rows || p.threads || p.tile_w || p.tile_h || !(p.term_type & HSFLOW_TERM_ITER) || p.max_iter <= 0 ||
+        px > 1500000LL || pl->width < 256 || pl->height < 80)
+        return p;
+    const int T = p.max_iter < 20 ? p.max_iter : 20, HX = (T + 3) / 4 * 4, CW = 256 - 2 * HX;
+    if (CW < 64) return p;
+    const int CH16 = 80 - 2 * T; // 16 wavefronts x 5 rows
+    const long long tiles16 = CH16 > 0 ? (long long)((pl->width + CW - 1) / CW) * ((pl->height + CH16 - 1) / CH16) : 0;
+    p.kernel = HSFLOW_KERNEL_STRIP;
+    p.fuse_steps = T;
+    p.strip_rows = 5;
+    p.threads = tiles16 >= 50 ? 1024 : 768;
+    return p;
 }
 
 int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
@@ -74,6 +103,8 @@ int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int hei
     hsflow_pipeline *pl = new (std::nothrow) hsflow_pipeline();
     if (!pl) return pfail(nullptr, HSFLOW_E_OOM, "host allocation failed");
     pl->slots.resize((size_t)depth);
+    pl->width = width;
+    pl->height = height;
     for (auto &s : pl->slots) {
         const int st = hsflow_create(&s.ctx, device, width, height, 1, nullptr, /*own_stream*/ 1);
         if (st) {
@@ -81,6 +112,7 @@ int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int hei
             hsflow_pipeline_destroy(pl);
             return st;
         }
+        hsflow_set_async_reduce(s.ctx, 1); // the slots' streams overlap: the witness words are reduced in-stream, settling is a wait and a look
         // HSFLOW_PIPELINE_CU_SHARE=<n>: every slot plans for n CUs (hsflow_set_cu_share) -- an experiment knob.  Off by
         // default: the planners' cost models were fitted to solves that have the chip to themselves, and with a share
         // they picked worse shapes than without at 1080p (0.161 against 0.139 ms per pair at depth 2) and at 600x480
@@ -128,7 +160,10 @@ int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *pr
         hsflow_synchronize(s.ctx); // one of the two uploads may have been queued already
         return ctx_fail(pl, s.ctx, st, "upload of the frames");
     }
-    if ((st = hsflow_solve_async(s.ctx, params))) {
+    hsflow_params shaped;
+    const hsflow_params *use = params; // (a struct of another size is not copied: hsflow_solve_async refuses it)
+    if (params->struct_size == sizeof(hsflow_params)) { shaped = stream_shape(pl, *params); use = &shaped; }
+    if ((st = hsflow_solve_async(s.ctx, use))) {
         hsflow_synchronize(s.ctx); // the uploads were queued: do not leave them reading caller memory
         return ctx_fail(pl, s.ctx, st, "hsflow_solve_async");
     }
@@ -156,7 +191,10 @@ int hsflow_pipeline_submit_device(hsflow_pipeline *pl, const void *d_prev, size_
         hsflow_synchronize(s.ctx);
         return ctx_fail(pl, s.ctx, st, "hsflow_set_frames_u8_device");
     }
-    if ((st = hsflow_solve_async(s.ctx, params))) {
+    hsflow_params shaped;
+    const hsflow_params *use = params; // (a struct of another size is not copied: hsflow_solve_async refuses it)
+    if (params->struct_size == sizeof(hsflow_params)) { shaped = stream_shape(pl, *params); use = &shaped; }
+    if ((st = hsflow_solve_async(s.ctx, use))) {
         hsflow_synchronize(s.ctx); // the frame copies were queued: do not leave them reading caller memory
         return ctx_fail(pl, s.ctx, st, "hsflow_solve_async");
     }

@@ -65,7 +65,8 @@ def test_bench_single_gpu_line(gpu_ok):
     # the workload the reference's authors ran (600x480 city pair, lambda 0.1, 100 iterations, blur first): latency, stream, end to end, CPU port
     rd = d["reference_default_workload"]
     assert "error" not in rd, rd
-    assert rd["latency"]["iterations_done"] == 100 and 0 < rd["stream_large_tiles"]["ms"] and 0 < rd["stream"]["ms"] and 0 < rd["end_to_end"]["ms"]
+    assert rd["latency"]["iterations_done"] == 100 and 0 < rd["stream_shape_by_hand"]["ms"] and 0 < rd["stream"]["ms"] and 0 < rd["end_to_end"]["ms"]
+    assert rd["stream"]["tiles"] == rd["stream_shape_by_hand"]["tiles"] and rd["stream"]["rows"] == 5   # the pipeline picks that shape itself
     assert rd["latency"]["ms"] < 0.2 and rd["cpu_port"]["cores"] == 1 and rd["cpu_port"]["ms"] > rd["latency"]["ms"]
     assert 0 < d["classic_mode"]["stream_ms_per_step"] < d["classic_mode"]["ms_per_step"] * 1.05
     cb = d["cpu_baseline"]

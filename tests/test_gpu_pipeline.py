@@ -318,7 +318,10 @@ def test_device_resident_stream_early_stop_while_the_next_pair_is_in_flight(hs, 
             u, v = pl.flow_device(tickets[j])
             info = pl.info(tickets[j])
             assert info["iterations_done"] == ref[k][1] and info["eps_rerun"] == (1 if ref[k][1] < budget else 0), (j, k, info)
-            assert np.array_equal(u.cpu().numpy(), ref[k][0][0]) and np.array_equal(v.cpu().numpy(), ref[k][0][1]), (j, k)
+            # (bit for bit; below 1e-30 -- reached only on the flat synthetic pair -- the strip kernels' scaled state keeps bits that
+            # depend on where the launch boundaries fall, and at depth >= 3 the pipeline picks its own launch shape: DESIGN.md 4.1)
+            for got, want in ((u.cpu().numpy(), ref[k][0][0]), (v.cpu().numpy(), ref[k][0][1])):
+                assert np.all((got == want) | ((np.abs(got) < 1e-30) & (np.abs(want) < 1e-30))), (j, k)
             if j + depth < len(order):
                 kk = order[j + depth]
                 tickets[j + depth] = pl.submit_device(dev[kk][0], dev[kk][1], params=p)
