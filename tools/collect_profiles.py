@@ -20,12 +20,19 @@ def find(pattern):
     return max(r, key=os.path.getmtime) if r else None  # newest run wins
 
 
-def counter_per_dispatch(path, counter, kernel_substr):
+def counter_per_dispatch(path, counter, kernel_substr, grid=None, wg=None):
+    """Counter values of the dispatches of one kernel; grid / wg: only launches of that grid and workgroup size (a bench run
+    also launches the same kernel on other frame sizes: the side figures)."""
     vals = []
     with open(path) as f:
         for row in csv.DictReader(f):
-            if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
-                vals.append(float(row["Counter_Value"]))
+            if row.get("Counter_Name") != counter or kernel_substr not in row.get("Kernel_Name", ""):
+                continue
+            if grid is not None and int(float(row.get("Grid_Size", 0))) != grid:
+                continue
+            if wg is not None and int(float(row.get("Workgroup_Size", 0))) != wg:
+                continue
+            vals.append(float(row["Counter_Value"]))
     return vals
 
 
@@ -46,8 +53,9 @@ def main():
     fetch = find(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"))
     write = find(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"))
     if fetch and write:
-        fv = counter_per_dispatch(fetch, "FETCH_SIZE", kern)
-        wv = counter_per_dispatch(write, "WRITE_SIZE", kern)
+        grid = out["tiles_per_launch"] * out["threads"]
+        fv = counter_per_dispatch(fetch, "FETCH_SIZE", kern, grid, out["threads"])
+        wv = counter_per_dispatch(write, "WRITE_SIZE", kern, grid, out["threads"])
         if fv and wv:
             # drop tail launches (fewer sweeps): keep the most common magnitude via the median
             fv.sort(); wv.sort()

@@ -8,7 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --blocks 2 --skip-cpu $*"
+# --loop repeat: one solve after the other on ONE stream, so that a kernel's duration in the trace is its duration alone on
+# the chip -- what bench.py's roofline prices (HIP events around eager launches); in the default stream loop two slots'
+# launches overlap and every kernel's wall time stretches.
+ARGS="--steps 20 --warmup 3 --blocks 2 --skip-cpu --loop repeat --no-side $*"   # (--no-side: no side figures on other frame sizes / streams in the trace)
 # 1) per-kernel durations (the command bench.py's roofline line is checked against)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err" || exit 1
 # 2) HBM traffic, one counter group per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass)
