@@ -17,12 +17,16 @@ bad = 0
 worst = 0.0
 near = 0
 refused = 0
+routed_persist = routed_pipe = 0
 t_start = time.time()
 for case in range(n_cases):
     W = int(rng.integers(1, 700)) if case % 4 else int(rng.integers(1, 40))
     H = int(rng.integers(1, 400)) if case % 5 else int(rng.integers(1, 12))
     N = int(rng.choice([1, 1, 1, 2, 3]))
     it = int(rng.integers(1, 80))
+    route = str(rng.choice(["ctx", "ctx", "ctx", "persist", "pipe"]))
+    if route == "persist" and case % 6 != 5:   # a frame the persistent launch can take: one region at least, width a multiple of 4
+        W, H, it = 4 * int(rng.integers(64, 176)), int(rng.integers(80, 400)), int(rng.integers(25, 80))
     lam = float(10.0 ** rng.uniform(-2.5, 1.5))
     use_eps = bool(rng.integers(0, 2))
     eps = float(10.0 ** rng.uniform(-7, -1))
@@ -77,21 +81,61 @@ for case in range(n_cases):
                     bad += 1
                     print("case %d: classic %dx%d N%d it%d alpha%.3g shipped%d %s pair %d MISMATCH" % (case, W, H, N, it, alpha, shipped, ckw, i), flush=True)
         continue
+    # round 3's routes beside the plain context: the persistent launch (where this shape can run it), and the device-resident
+    # pair pipeline (one pair, cold start: every pair is its own solve there)
+    if route == "persist" and (kernel not in (hs.KERNEL_AUTO, hs.KERNEL_STRIP) or (use_eps and not do_async)):
+        route = "ctx"
+    if route == "pipe" and (N != 1 or warm or kernel in (hs.KERNEL_SIMPLE, hs.KERNEL_FUSED) and use_eps):
+        route = "ctx"
     try:
-        with hs.HSFlow(W, H, N, own_stream=True) as ctx:
-            for i, (A, B) in enumerate(pairs):
-                ctx.set_frames(A, B, pair=i)
-            first = it // 2 if warm else 0
-            if warm:
-                ctx.solve(lam=lam, max_iter=first, term_type=ITER, **kw)
-            p = ctx.make_params(lam=lam, max_iter=it - first, epsilon=eps, term_type=tt, use_previous=warm, reuse_derivatives=warm, use_graph=graph, **kw)
-            if do_async:
-                ctx.solve_async(p)
-                ctx.synchronize()
-                info = ctx.info()
-            else:
-                info = ctx.solve(p)
-            flows = [ctx.flow(pair=i) for i in range(N)]
+        if route == "pipe":
+            import torch
+            first = 0
+            p = hs.make_params(lam=lam, max_iter=it, epsilon=eps, term_type=tt, use_graph=graph, **kw)
+            dA, dB = torch.from_numpy(pairs[0][0]).cuda(), torch.from_numpy(pairs[0][1]).cuda()
+            with hs.PairPipeline(W, H, depth=int(rng.integers(2, 5))) as pl:
+                t0_ = pl.submit_device(dA, dB, params=p)
+                t1_ = pl.submit_device(dA, dB, params=p)   # a second pair behind it: the first one's check is owed meanwhile
+                u_, v_ = pl.flow_device(t0_)
+                info = pl.info(t0_)
+                flows = [(u_.cpu().numpy(), v_.cpu().numpy())]
+                u2_, v2_ = pl.flow_device(t1_)
+                if not (np.array_equal(u2_.cpu().numpy(), flows[0][0]) and np.array_equal(v2_.cpu().numpy(), flows[0][1])) or \
+                        pl.info(t1_)["iterations_done"] != info["iterations_done"]:
+                    bad += 1
+                    print("case %d: pipeline slots disagree on the same pair" % case, flush=True)
+            routed_pipe += 1
+        else:
+            with hs.HSFlow(W, H, N, own_stream=True) as ctx:
+                for i, (A, B) in enumerate(pairs):
+                    ctx.set_frames(A, B, pair=i)
+                first = it // 2 if warm else 0
+                kw_run = dict(kw)
+                if route == "persist":
+                    kw_run.update(kernel=hs.KERNEL_PERSIST, strip_rows=5)
+                if warm:
+                    ctx.solve(lam=lam, max_iter=first, term_type=ITER, **kw)
+                while True:
+                    p = ctx.make_params(lam=lam, max_iter=it - first, epsilon=eps, term_type=tt, use_previous=warm, reuse_derivatives=warm, use_graph=graph, **kw_run)
+                    try:
+                        if do_async:
+                            ctx.solve_async(p)
+                            ctx.synchronize()
+                            info = ctx.info()
+                        else:
+                            info = ctx.solve(p)
+                        break
+                    except hs.HsflowError as e:
+                        if kw_run.get("kernel") == hs.KERNEL_PERSIST and e.status == hs._lib.E_SIZE:   # this shape has no persistent form
+                            kw_run = dict(kw)
+                            continue
+                        raise
+                if kw_run.get("kernel") == hs.KERNEL_PERSIST:
+                    routed_persist += 1
+                    if not (info["persistent"] >= 2 or info["eps_rerun"]):   # (an exact pass that settles an ITER|EPS solve runs launch by launch)
+                        bad += 1
+                        print("case %d: asked for the persistent launch, got %r" % (case, info), flush=True)
+                flows = [ctx.flow(pair=i) for i in range(N)]
     except hs.HsflowError as e:
         print("case %d: %dx%d N%d it%d k%d %s -> ERROR %s" % (case, W, H, N, it, kernel, kw, e), flush=True)
         bad += 1
@@ -147,5 +191,6 @@ for case in range(n_cases):
               (case, W, H, N, it, lam, ("%.3g" % eps) if use_eps else "-", kernel, kw, graph, do_async, warm, info["iterations_done"], worst, e_batch), flush=True)
     if case % 25 == 24:
         print("... %d cases, %d bad, worst rms %.3g, %.0f s" % (case + 1, bad, worst, time.time() - t_start), flush=True)
-print("DONE %d cases, %d bad, worst rms %.3g, %d near-threshold, %d classic strip shapes refused (no aligned form)" % (n_cases, bad, worst, near, refused))
+print("DONE %d cases, %d bad, worst rms %.3g, %d near-threshold, %d classic strip shapes refused (no aligned form); %d through the persistent launch, %d through the device-resident pipeline"
+      % (n_cases, bad, worst, near, refused, routed_persist, routed_pipe))
 sys.exit(1 if bad else 0)
