@@ -538,13 +538,26 @@ int hsflow_slab_solve(hsflow_slab *s, const hsflow_params *pp)
         if (!use_eps) {
             if ((st = chunk_async(s, *pp, chunk, from_zero, first, HSFLOW_TERM_ITER))) return st;
         } else if (!measure) {
-            if ((st = chunk_async(s, *pp, chunk, from_zero, first, HSFLOW_TERM_ITER | HSFLOW_TERM_EPS))) return st;
             bool vouched = false;
-            for (Slab &sl : s->slabs) {
-                SL_HIP(s, hipSetDevice(sl.device));
-                int proven = 0;
-                SL_CTX(s, sl, hsflow_take_verdict(sl.ctx, &proven));
-                vouched = vouched || proven != 0;
+            st = chunk_async(s, *pp, chunk, from_zero, first, HSFLOW_TERM_ITER | HSFLOW_TERM_EPS);
+            if (st == HSFLOW_E_ARG) {
+                // a slab whose launch plan cannot run witness launches (a core tile thinner than a strip: very thin slabs):
+                // nobody vouches, the solve is measured from here on (the replay below also undoes what the other slabs
+                // may already have enqueued for this chunk)
+                for (Slab &sl : s->slabs) { // (their owed checks, if any, are dropped with the flow they belong to)
+                    SL_HIP(s, hipSetDevice(sl.device));
+                    int proven = 0;
+                    (void)hsflow_take_verdict(sl.ctx, &proven);
+                }
+            } else if (st) {
+                return st;
+            } else {
+                for (Slab &sl : s->slabs) {
+                    SL_HIP(s, hipSetDevice(sl.device));
+                    int proven = 0;
+                    SL_CTX(s, sl, hsflow_take_verdict(sl.ctx, &proven));
+                    vouched = vouched || proven != 0;
+                }
             }
             if (!vouched) { // back to this chunk's start, then measure
                 measure = true;

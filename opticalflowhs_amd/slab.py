@@ -283,8 +283,14 @@ class SlabSolver(object):
             if eps is None:
                 run(i, n, False)
             elif not measure:
-                run(i, n, True)
-                if self._all_max([1.0 if b.verdict() else 0.0])[0] < 0.5:   # nobody vouches for this chunk
+                try:
+                    run(i, n, True)
+                    mine = 1.0 if b.verdict() else 0.0
+                except Exception as e:  # noqa: BLE001 -- a launch plan that cannot run witness launches (a very thin slab): no voucher
+                    if getattr(e, "status", None) != 1:   # HSFLOW_E_ARG
+                        raise
+                    mine = 0.0
+                if self._all_max([mine])[0] < 0.5:   # nobody vouches for this chunk
                     measure = self.eps_measured = True
                     if start is not None:
                         b.restore(start)
