@@ -69,7 +69,9 @@ def parse():
                     help="what a step is: `stream` = a NEW resident pair every step through the device-resident pair pipeline (two seed pairs "
                          "alternating; every pair pays its frame copy, derivative pass and its own early-stop check) -- the default for one pair "
                          "per step with the strip / fold kernels; `repeat` = the same resident batch solved again on one context")
-    ap.add_argument("--stream-depth", type=int, default=2, help="slots of the pair pipeline in the `stream` loop")
+    ap.add_argument("--stream-depth", type=int, default=6, help="slots of the pair pipeline in the `stream` loop")
+    ap.add_argument("--stream-lanes", type=int, default=2, help="streams those slots are spread over (two solves side by side fill the chip's "
+                                                                 "gaps; the further slots keep both streams' queues full)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the single-thread cpu_baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0: same as --iters)")
@@ -145,7 +147,7 @@ def run_fresh_frames(args, hs, synth, torch, local_rank, W, H, iters, p_ieps, ba
         A, B = synth.translating_pair(W, H, seed=sd)
         seeds.append((torch.from_numpy(A).to("cuda:%d" % local_rank), torch.from_numpy(B).to("cuda:%d" % local_rank)))
     torch.cuda.synchronize()
-    with hs.PairPipeline(W, H, depth=depth, device=local_rank) as pl:
+    with hs.PairPipeline(W, H, depth=depth, device=local_rank, lanes=min(args.stream_lanes, depth)) as pl:
         def run(n):
             for k in range(n):
                 a, b = seeds[k & 1]
@@ -451,7 +453,7 @@ def main():
         A2, B2 = synth.translating_pair(W, H, seed=s0 + 1)
         dev_pairs.append((torch.from_numpy(A2).to("cuda:%d" % local_rank), torch.from_numpy(B2).to("cuda:%d" % local_rank)))
         torch.cuda.synchronize()
-        pl = hs.PairPipeline(W, H, depth=args.stream_depth, device=local_rank)
+        pl = hs.PairPipeline(W, H, depth=args.stream_depth, device=local_rank, lanes=min(args.stream_lanes, args.stream_depth))
         n_sub = [0]
 
         def stepper(p):  # noqa: F811 -- the stream loop's step: submit the next pair (blocks only while its slot is still busy)
@@ -633,7 +635,7 @@ def main():
                    "threads": info["threads"], "rows_per_lane_or_groups": info["groups_per_thread"], "tiles_per_launch": info["tiles"],
                    "lds_bytes": info["lds_bytes"], "hipgraph": not args.no_graph, "termination": head_name,
                    "loop": loop,
-                   "call": ("hsflow_pipeline_submit_device, %d slots (one stream each)" % args.stream_depth) if pl else
+                   "call": ("hsflow_pipeline_submit_device, %d slots on %d streams" % (args.stream_depth, min(args.stream_lanes, args.stream_depth))) if pl else
                            ("hsflow_solve" if args.sync_solves else "hsflow_solve_async"),
                    "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"],
                    "eps_check": "n/a (ITER)" if args.iter_only else (
@@ -680,6 +682,7 @@ def main():
         out["single_context"] = single
         if not args.iter_only:  # the headline IS that loop
             out["fresh_frames"] = {"is_the_headline": True, "ms_per_step": ms_per_step, "value": value, "unit": "Mpix*iter/s", "depth": args.stream_depth,
+                                   "lanes": min(args.stream_lanes, args.stream_depth),
                                    "iterations_done": info["iterations_done"], "eps_rerun": info["eps_rerun"],
                                    "what": "a different resident pair every step, ITER|EPS (eps 1e-6), hsflow_pipeline_submit_device"}
         pl.close()
@@ -706,7 +709,7 @@ def main():
             ic = ctx.info()
             stream_ms = None
             if pl_ok:
-                with hs.PairPipeline(W, H, depth=2, device=local_rank) as plc:
+                with hs.PairPipeline(W, H, depth=args.stream_depth, device=local_rank, lanes=min(args.stream_lanes, args.stream_depth)) as plc:
                     pcg = ctx.make_params(mode=hs.MODE_CLASSIC, alpha=15.0, max_iter=iters, term_type=hs.TERM_ITER, use_graph=True)
 
                     def goc(k):
@@ -718,7 +721,7 @@ def main():
                     goc(nc)
                     stream_ms = (time.perf_counter() - t0) / nc * 1e3
             out["classic_mode"] = {"what": "Kernels.cl discretisation (v update restored), alpha 15, ITER, %d sweeps, same frames" % iters,
-                                   "stream_ms_per_step": stream_ms, "stream_what": "a new resident pair every step through the two-slot pair pipeline",
+                                   "stream_ms_per_step": stream_ms, "stream_what": "a new resident pair every step through the pair pipeline (the headline's slots and streams)",
                                    "ms_per_step": cms, "value": px * iters / (cms * 1e-3) / 1e6, "unit": "Mpix*iter/s",
                                    "kernel": {hs.KERNEL_STRIP: "strip", hs.KERNEL_FUSED: "fused", hs.KERNEL_SIMPLE: "simple"}.get(ic["kernel"], str(ic["kernel"])),
                                    "fuse_steps": ic["fuse_steps"], "rows_per_lane_or_groups": ic["groups_per_thread"], "threads": ic["threads"],

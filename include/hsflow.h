@@ -167,11 +167,18 @@ int hsflow_set_row_origin(hsflow_ctx *ctx, int first_row);
 int hsflow_set_cu_share(hsflow_ctx *ctx, int compute_units);
 
 /* on != 0: an asynchronous ITER|EPS solve enqueues the reduction of its witness words right behind its last launch (a
- * small kernel per solve on the context's stream) instead of leaving it to whoever settles the check: settling then costs
- * the host a wait and a look, no launch and no second round trip.  Pays where the stream is not the bottleneck -- the
+ * small kernel per solve on the context's stream) instead of leaving it to whoever settles the check, and EVERY asynchronous
+ * solve is followed by a one-thread kernel that writes a running count to page-locked memory: settling and hsflow_wait_solve
+ * then poll that word -- no launch, no stream-wide wait, no event record (which costs a stream of solves 6 %).  Pays where the stream is not the bottleneck -- the
  * slots of a pair pipeline set it: their streams overlap, and for small frames the host's time per pair is what bounds
  * the stream.  Off by default: back-to-back solves on ONE stream would pay the kernel and its boundary every time. */
 int hsflow_set_async_reduce(hsflow_ctx *ctx, int on);
+
+/* Waits until the last solve of THIS context has finished and settles the early-stop check it may owe.  With
+ * hsflow_set_async_reduce on, that is a poll of the marker behind the solve: unlike hsflow_synchronize it does not wait for
+ * what other contexts have enqueued on the same stream since (the slots of a pair pipeline share streams); without it,
+ * the same as hsflow_synchronize. */
+int hsflow_wait_solve(hsflow_ctx *ctx);
 
 /* --- building blocks for drivers that run ONE solve over several contexts (row slabs, hsflow_slab_*) ----------- */
 
@@ -301,6 +308,13 @@ int hsflow_host_unregister(void *p);
  * Single-owner like a context; one pipeline per (thread, device). */
 typedef struct hsflow_pipeline hsflow_pipeline;
 int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int height, int depth);
+/* The same with the `depth` slots spread over `lanes` streams (slot k on stream k mod lanes; 1 <= lanes <= depth;
+ * hsflow_pipeline_create: lanes = depth, which is what host-memory pairs want -- upload, solve and download of three
+ * pairs on three queues).  For pairs that are already in device memory TWO lanes with 4 - 8 slots are the shape to use:
+ * two solves side by side is what fills the chip's gaps, and the further slots keep both streams' queues
+ * full while the host settles and refills the oldest slot -- 0.125 ms per 1080p / 100 pair against 0.139 with two slots
+ * on two streams. */
+int hsflow_pipeline_create_lanes(hsflow_pipeline **out, int device, int width, int height, int depth, int lanes);
 int hsflow_pipeline_destroy(hsflow_pipeline *pl); /* drains first; NULL accepted */
 /* ticket (optional out): 0, 1, 2, ... in submission order.  Blocks only while the slot it is
  * about to reuse (ticket - depth) is still running. */

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "hsflow_solve": (_i, [_vp, _pp]),
     "hsflow_solve_async": (_i, [_vp, _pp]),
     "hsflow_synchronize": (_i, [_vp]),
+    "hsflow_wait_solve": (_i, [_vp]),
     "hsflow_get_flow": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_get_flow_async": (_i, [_vp, _i, _vp, _sz, _vp, _sz]),
     "hsflow_flow_view_device": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "hsflow_host_register": (_i, [_vp, _sz]),
     "hsflow_host_unregister": (_i, [_vp]),
     "hsflow_pipeline_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i]),
+    "hsflow_pipeline_create_lanes": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _i]),
     "hsflow_pipeline_destroy": (_i, [_vp]),
     "hsflow_pipeline_submit": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),
     "hsflow_pipeline_submit_ex": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _pp, ctypes.POINTER(ctypes.c_uint64)]),

@@ -46,6 +46,30 @@ struct GraphEntry {
     int cur_after, launches;
 };
 
+// What solve_impl works out once and the three termination paths share.
+struct SolveSetup {
+    float coeff;        // Ilambda = fl32(1 / fl32(lambda))
+    int kernel;         // kernel actually used (AUTO resolved)
+    bool multi;         // several sweeps per launch (every kernel but the simple one)
+    bool use_iter, use_eps;
+    long long budget;   // sweep budget (huge when ITER does not apply)
+    int T;              // sweeps per full launch
+    JPlan plan;         // launch plan for T sweeps
+    bool persist;       // the whole budget as ONE persistent launch in phases of T sweeps (HSFLOW_KERNEL_PERSIST)
+    hsflow_params eff;  // the caller's parameters as the solve paths use them (strip_rows may have been fixed, see prepare_solve)
+};
+
+// prepare_solve's result for one set of parameters (hsflow_ctx::plan_cache)
+struct PlanKey {
+    hsflow_params p;
+    int async, exact;
+};
+struct PlanEntry {
+    PlanKey key;
+    SolveSetup S;
+    hsflow_info info;
+};
+
 } // namespace
 
 struct hsflow_ctx {
@@ -84,6 +108,11 @@ struct hsflow_ctx {
     bool counted = false;        // this context is in g_live_ctx
     int eps_row0 = 0, eps_rows = 0; // hsflow_set_eps_rows: rows whose changes count for Eps (0 rows: the whole frame)
     std::vector<float> sweep_eps;   // Eps of every sweep of the last exact (per-sweep) pass: hsflow_solve_probe hands it out
+    // hsflow_set_async_reduce: every asynchronous solve is followed by k_mark_done; the host waits for a solve by polling the
+    // page-locked word (hsflow_wait_solve) instead of waiting for the stream
+    unsigned *dSeq = nullptr, *hMark = nullptr, *hMarkDev = nullptr;
+    unsigned mark_issued = 0;       // markers enqueued so far = the value the last one will write
+    bool last_marked = false;       // the last solve was followed by a marker
     bool async_reduce = false;      // hsflow_set_async_reduce
     int cu_share = 0;            // > 0: the planners count on this many CUs only (hsflow_set_cu_share); 0: the whole chip
     int num_cu = 0;              // compute units of the device (one workgroup of the persistent launch per CU)
@@ -101,6 +130,8 @@ struct hsflow_ctx {
         int iters = 0, slots = 0, launches = 0, cur0 = 0;
         int stride = 1, n_first = 0, cnt_first = 0, cnt_last = 0; // layout of its witness words (k_eps_reduce's arguments)
         bool reduced = false;   // the reduction into hEps was enqueued with the solve (async_reduce)
+        unsigned mark = 0;      // ... and the marker behind it
+        bool marked_by_reduce = false; // ... written by the reduction kernel's last workgroup
     } pend;
     // what it takes to measure last_eps of an asynchronous ITER|EPS solve on demand (hsflow_get_info): its last
     // launch again, from the input buffer that launch left intact, with the final sweep's Eps measured
@@ -113,6 +144,7 @@ struct hsflow_ctx {
     } lastl;
     bool force_exact = false; // the exact per-sweep pass is wanted (set while a pending solve is settled)
     std::map<GraphKey, GraphEntry> graphs;
+    std::vector<PlanEntry> plan_cache; // prepare_solve's results by parameters; cleared when what they rest on changes
     std::vector<hipEvent_t> events;
 };
 

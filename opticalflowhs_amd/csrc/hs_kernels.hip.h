@@ -480,8 +480,11 @@ namespace hsk {
 // Row r holds cnt_first valid words for r < n_first, else cnt_last (launches of different plans have
 // different workgroup counts; words beyond are never read, so nothing needs clearing).  `out` is
 // page-locked host memory seen through its device address: the words are on the host when the stream drains.
+// seq / host_mark (may be null): the last of the kernel's workgroups to finish also plays k_mark_done (below) -- an asynchronous
+// ITER|EPS solve of a marked context (hsflow_set_async_reduce) then needs no marker kernel of its own.
 __global__ __launch_bounds__(256) void k_eps_reduce(const unsigned *__restrict__ tiles, int stride,
-                                                    unsigned *__restrict__ out, int n_first, int cnt_first, int cnt_last)
+                                                    unsigned *__restrict__ out, int n_first, int cnt_first, int cnt_last,
+                                                    unsigned *__restrict__ seq, unsigned *__restrict__ host_mark)
 {
     __shared__ unsigned part[4];
     const unsigned *row = tiles + (size_t)blockIdx.x * stride;
@@ -494,6 +497,27 @@ __global__ __launch_bounds__(256) void k_eps_reduce(const unsigned *__restrict__
     if (threadIdx.x == 0) {
         out[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
         __threadfence_system();
+        if (seq) { // (every workgroup's word is on the host before its count: the last one's marker comes after all of them)
+            if (atomicAdd(&seq[1], 1u) == gridDim.x - 1u) {
+                seq[1] = 0u;
+                const unsigned s = seq[0] + 1u;
+                seq[0] = s;
+                __hip_atomic_store(host_mark, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// "Everything this context enqueued before me is done": counts up a device word and writes the count to page-locked host
+// memory, where the host polls it (hsflow_wait_solve of a context whose stream is shared: a stream-wide wait would also
+// wait for what other contexts queued later, and an event record between the solves of a stream costs the stream 6 %,
+// tools/event_cost.py).
+__global__ void k_mark_done(unsigned *__restrict__ seq, unsigned *__restrict__ host_mark)
+{
+    if (threadIdx.x == 0) {
+        const unsigned s = seq[0] + 1u;
+        seq[0] = s;
+        __hip_atomic_store(host_mark, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

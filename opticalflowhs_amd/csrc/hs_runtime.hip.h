@@ -27,6 +27,9 @@ int check_ctx(hsflow_ctx *c, int pair)
     if (!c) return fail(nullptr, HSFLOW_E_ARG, "null context");
     if (pair < 0 || pair >= c->N) return fail(c, HSFLOW_E_ARG, "pair index out of range");
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, HSFLOW_E_DEVICE, "hipSetDevice failed");
+    // The launch wrappers report hipGetLastError() after a launch; that is the LAST error of this host thread, so a HIP call
+    // that failed earlier -- anywhere in the process, already reported to its own caller -- must not surface here.
+    (void)hipGetLastError();
     return HSFLOW_OK;
 }
 
@@ -112,6 +115,7 @@ void persist_failed(hsflow_ctx *c)
     c->persist_tiles = 0;
     c->persist_off = true;
     c->persist_unchecked = false;
+    c->plan_cache.clear();
 }
 
 // Did the last persistent launch(es) of this context give up?  Only meaningful once the stream has drained.
@@ -234,10 +238,11 @@ int eps_prepare(hsflow_ctx *c, int sweeps, int stride)
 // Reduces the rows of per-workgroup words to one word per row, straight into the host's buffer (no copy
 // node).  Rows [0, n_first) hold cnt_first valid words, the others cnt_last (defaults: every row is
 // epsStride words, which then must have been cleared where a launch had fewer workgroups).
-int eps_collect_enqueue(hsflow_ctx *c, int sweeps, int n_first = 0, int cnt_first = 0, int cnt_last = -1)
+// mark: the kernel's last workgroup also writes the context's marker (hsflow_set_async_reduce; the caller counts it).
+int eps_collect_enqueue(hsflow_ctx *c, int sweeps, int n_first = 0, int cnt_first = 0, int cnt_last = -1, bool mark = false)
 {
     hipLaunchKernelGGL(hsk::k_eps_reduce, dim3(sweeps), dim3(256), 0, c->stream, c->dEpsTiles, c->epsStride, c->hEpsDev,
-                       n_first, cnt_first, cnt_last < 0 ? c->epsStride : cnt_last);
+                       n_first, cnt_first, cnt_last < 0 ? c->epsStride : cnt_last, mark ? c->dSeq : nullptr, mark ? c->hMarkDev : nullptr);
     HS_HIP(c, hipGetLastError());
     c->epsPtr = c->dEps;
     c->epsStride = 1;

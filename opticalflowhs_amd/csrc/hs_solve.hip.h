@@ -22,6 +22,22 @@ int check_persist(hsflow_ctx *c)
 
 // verdict_only: report whether the witness words prove "no early stop" and leave it at that (no exact pass; the flow of
 // the whole budget stands) -- for a driver that decides over several contexts (row slabs: hsflow_take_verdict).
+// Waits until the marker kernel that wrote `target` has run (k_mark_done: everything enqueued before it is done, and what the
+// reduction kernel wrote to host memory is visible).  Polls page-locked memory; gives the stream a proper wait after 2 s.
+int wait_marker(hsflow_ctx *c, unsigned target)
+{
+    if (!c->hMark) { HS_HIP(c, hipStreamSynchronize(c->stream)); return HSFLOW_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while ((int)(__atomic_load_n(c->hMark, __ATOMIC_ACQUIRE) - target) < 0) {
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HS_HIP(c, hipStreamSynchronize(c->stream));
+            break;
+        }
+    }
+    return HSFLOW_OK;
+}
+
 int settle_pending(hsflow_ctx *c, int *verdict_only = nullptr)
 {
     if (!c->pend.active) return HSFLOW_OK;
@@ -34,8 +50,13 @@ int settle_pending(hsflow_ctx *c, int *verdict_only = nullptr)
         c->epsStride = c->pend.stride;
         int st0 = eps_collect_enqueue(c, c->pend.slots, c->pend.n_first, c->pend.cnt_first, c->pend.cnt_last);
         if (st0) return st0;
+        HS_HIP(c, hipStreamSynchronize(c->stream));
+    } else {
+        // ... and a marker behind it: only THAT is waited for, not what other contexts may have enqueued on the same stream
+        // since (the slots of a pair pipeline share streams: pair_pipeline.cpp)
+        int stw = wait_marker(c, c->pend.mark);
+        if (stw) return stw;
     }
-    HS_HIP(c, hipStreamSynchronize(c->stream));
     float last = 0.f;
     const bool gave_up = c->persist_unchecked && persist_error(c); // a persistent launch that timed out proves nothing
     c->persist_unchecked = false;
@@ -300,18 +321,6 @@ int solve_classic(hsflow_ctx *c, const hsflow_params &p, bool async)
     return HSFLOW_OK;
 }
 
-// What solve_impl works out once and the three termination paths share.
-struct SolveSetup {
-    float coeff;        // Ilambda = fl32(1 / fl32(lambda))
-    int kernel;         // kernel actually used (AUTO resolved)
-    bool multi;         // several sweeps per launch (every kernel but the simple one)
-    bool use_iter, use_eps;
-    long long budget;   // sweep budget (huge when ITER does not apply)
-    int T;              // sweeps per full launch
-    JPlan plan;         // launch plan for T sweeps
-    bool persist;       // the whole budget as ONE persistent launch in phases of T sweeps (HSFLOW_KERNEL_PERSIST)
-    hsflow_params eff;  // the caller's parameters as the solve paths use them (strip_rows may have been fixed, see prepare_solve)
-};
 
 // ITER termination: a fixed sweep count, nothing on the host between launches (optionally one hipGraph).
 int solve_fixed(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, Profiler &prof, bool async)
@@ -509,8 +518,9 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
                 c->epsStride = 1;
                 return HSFLOW_OK;
             }
+            // (an asynchronous solve gets here only with the in-stream reduction on: its last workgroup writes the marker too)
             return eps_collect_enqueue(c, slots, n_launch - 1, plan_eps_stride(kernel, plan),
-                                       plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan));
+                                       plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan), async && c->hMark != nullptr);
         };
         if (p.use_graph && !p.profile) {
             GraphKey key{p.mode, persist ? HSFLOW_KERNEL_PERSIST : kernel, iters, T, c->info.tile_w, c->info.tile_h, c->info.threads,
@@ -567,6 +577,7 @@ int solve_iter_eps(hsflow_ctx *c, const hsflow_params &p, const SolveSetup &S, P
             c->pend.stride = stride; c->pend.n_first = n_launch - 1; c->pend.cnt_first = plan_eps_stride(kernel, plan);
             c->pend.cnt_last = plan_eps_stride(kernel, (last_chunk != T && !persist) ? tailp : plan);
             c->pend.reduced = c->async_reduce;
+            c->pend.marked_by_reduce = c->async_reduce && c->hMark != nullptr;
             c->info.iterations_done = iters;
             c->info.jacobi_launches = launches;
             return HSFLOW_OK;
@@ -860,6 +871,16 @@ int solve_impl(hsflow_ctx *c, const hsflow_params *pp, bool async)
     bool took_over = false;
     const int st = solve_impl_inner(c, pp, async, &took_over);
     if (st && took_over && !c->pend.active) c->pend = owed;
+    if (c) c->last_marked = false;
+    if (!st && async && c->async_reduce && c->hMark) { // a marker behind everything this solve enqueued (hsflow_wait_solve, settle_pending)
+        const bool by_reduce = c->pend.active && c->pend.marked_by_reduce; // (the reduction kernel of an ITER|EPS solve wrote it)
+        if (!by_reduce) hipLaunchKernelGGL(hsk::k_mark_done, dim3(1), dim3(64), 0, c->stream, c->dSeq, c->hMarkDev);
+        if (by_reduce || hipGetLastError() == hipSuccess) {
+            c->mark_issued++;
+            c->last_marked = true;
+            if (c->pend.active) c->pend.mark = c->mark_issued;
+        } else if (c->pend.active) c->pend.reduced = false; // (no marker: the owed check is settled the slow way)
+    }
     return st;
 }
 
@@ -885,8 +906,35 @@ int solve_impl_inner(hsflow_ctx *c, const hsflow_params *pp, bool async, bool *t
     if (p.mode != HSFLOW_MODE_CV) return fail(c, HSFLOW_E_ARG, "unknown mode");
     c->info.eps_rerun = 0;
     c->info.deriv_fused = 0;
+    // The plan of a solve depends on the parameters, not on the frames: a stream of solves with the same parameters plans
+    // once (the planner tries every sweep count x rows x wavefronts: tens of microseconds of host time per solve, which is
+    // what bounded a stream of small frames).  Not cached: a persistent launch (it depends on who else is alive).
     SolveSetup S;
-    if ((st = prepare_solve(c, p, async, S))) return st;
+    PlanKey key;
+    std::memset(&key, 0, sizeof(key)); // (compared bytewise: padding too)
+    key.p = p;
+    key.p.use_previous = key.p.reuse_derivatives = key.p.use_graph = key.p.profile = 0; // (do not enter the plan)
+    key.async = async ? 1 : 0;
+    key.exact = c->force_exact ? 1 : 0;
+    const bool cacheable = p.kernel != HSFLOW_KERNEL_PERSIST && !getenv("HSFLOW_PERSIST_AUTO");
+    const PlanEntry *hit = nullptr;
+    if (cacheable)
+        for (const PlanEntry &e : c->plan_cache)
+            if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { hit = &e; break; }
+    if (hit) {
+        S = hit->S;
+        S.eff = p; // (the cached copy carries the first caller's use_previous / reuse_derivatives / use_graph)
+        hsflow_info &i = c->info;
+        const hsflow_info &j = hit->info;
+        i.kernel = j.kernel; i.fuse_steps = j.fuse_steps; i.tile_w = j.tile_w; i.tile_h = j.tile_h; i.threads = j.threads;
+        i.groups_per_thread = j.groups_per_thread; i.tiles = j.tiles; i.lds_bytes = j.lds_bytes; i.persistent = j.persistent;
+    } else {
+        if ((st = prepare_solve(c, p, async, S))) return st;
+        if (cacheable) {
+            if (c->plan_cache.size() >= 16) c->plan_cache.erase(c->plan_cache.begin());
+            c->plan_cache.push_back(PlanEntry{key, S, c->info});
+        }
+    }
     c->info.deriv_ms = c->info.jacobi_ms = c->info.solve_ms = 0.f;
     c->info.last_eps = 0.f;
     Profiler prof{c, p.profile != 0};

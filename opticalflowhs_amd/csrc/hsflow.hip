@@ -12,6 +12,7 @@
 #include "hs_kernels_classic_strip.hip.h"
 
 #include <atomic>
+#include <chrono>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -175,6 +176,7 @@ int hsflow_set_row_origin(hsflow_ctx *c, int first_row)
     const int org = first_row & 1;
     if (org != c->org) {
         drop_graphs(c); // captured launches carry the phase (kernel choice and geometry)
+        c->plan_cache.clear();
         c->lastl.valid = false;
         c->org = org;
     }
@@ -190,6 +192,7 @@ int hsflow_set_cu_share(hsflow_ctx *c, int compute_units)
     if (share != c->cu_share) {
         if ((st = settle_pending(c))) return st;
         c->cu_share = share; // (graphs are keyed by the launch shape, so cached ones stay valid)
+        c->plan_cache.clear();
     }
     return HSFLOW_OK;
 }
@@ -210,6 +213,8 @@ int hsflow_destroy(hsflow_ctx *c)
     hipFree(c->dEps);
     hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dUp); hipFree(c->dVp); hipFree(c->dFlags);
+    hipFree(c->dSeq);
+    if (c->hMark) hipHostFree(c->hMark);
     if (c->hErr) hipHostFree(c->hErr);
     if (c->counted) g_live_ctx[c->device & 63]--;
     hipFree(c->dStamps);
@@ -392,6 +397,15 @@ int hsflow_set_async_reduce(hsflow_ctx *c, int on)
     int st = check_ctx(c, 0);
     if (st) return st;
     if ((st = settle_pending(c))) return st;
+    if (on && !c->hMark) { // the marker word (page-locked, device-visible) and its device-side counter
+        HS_HIP(c, hipMalloc((void **)&c->dSeq, 2 * sizeof(unsigned)));
+        HS_HIP(c, hipMemsetAsync(c->dSeq, 0, 2 * sizeof(unsigned), c->stream));
+        HS_HIP(c, hipHostMalloc((void **)&c->hMark, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HS_HIP(c, hipHostGetDevicePointer((void **)&c->hMarkDev, c->hMark, 0));
+        *c->hMark = 0u;
+        c->mark_issued = 0;
+    }
+    c->last_marked = false;
     c->async_reduce = on != 0;
     return HSFLOW_OK;
 }
@@ -405,6 +419,7 @@ int hsflow_set_eps_rows(hsflow_ctx *c, int first_row, int rows)
     const int r0 = rows > 0 ? first_row : 0, n = rows > 0 ? rows : 0;
     if (r0 != c->eps_row0 || n != c->eps_rows) {
         drop_graphs(c); // captured launches carry the window in their geometry
+        c->plan_cache.clear();
         c->lastl.valid = false;
         c->eps_row0 = r0;
         c->eps_rows = n;
@@ -446,6 +461,18 @@ int hsflow_take_verdict(hsflow_ctx *c, int *proven)
 
 int hsflow_solve(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, false); }
 int hsflow_solve_async(hsflow_ctx *c, const hsflow_params *p) { return solve_impl(c, p, true); }
+
+int hsflow_wait_solve(hsflow_ctx *c)
+{
+    int st = check_ctx(c, 0);
+    if (st) return st;
+    // (with the witness words reduced in-stream the owed check is settled by waiting for the solve's event; otherwise
+    // settle_pending enqueues the reduction and waits for the stream)
+    if ((st = settle_pending(c))) return st;
+    if (c->last_marked) { if ((st = wait_marker(c, c->mark_issued))) return st; }
+    else HS_HIP(c, hipStreamSynchronize(c->stream));
+    return check_persist(c);
+}
 
 int hsflow_synchronize(hsflow_ctx *c)
 {
@@ -500,7 +527,8 @@ int hsflow_flow_view_device(hsflow_ctx *c, int pair, const float **du, const flo
     if (st) return st;
     if (!du || !dv || !stride_bytes) return fail(c, HSFLOW_E_ARG, "null out pointer");
     if ((st = settle_pending(c))) return st;
-    HS_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->last_marked) { if ((st = wait_marker(c, c->mark_issued))) return st; } // (the flow is final behind the last solve)
+    else HS_HIP(c, hipStreamSynchronize(c->stream));
     if ((st = check_persist(c))) return st;
     *du = c->dU[c->cur] + pair * c->plane;
     *dv = c->dV[c->cur] + pair * c->plane;

@@ -8,6 +8,8 @@
 // C ABI, so it is also the example of how a host drives several contexts from one thread.
 #include "../../include/hsflow.h"
 
+#include <hip/hip_runtime.h>
+
 #include <cstdlib>
 #include <new>
 #include <string>
@@ -23,8 +25,12 @@ struct hsflow_pipeline {
         hsflow_info done;                 // of the last job that finished on this slot
         bool has_done = false;
         uint64_t done_ticket = 0;
+        hipStream_t stream = nullptr;     // the lane this slot works on (shared with the slots k +- lanes)
+        hipEvent_t ev = nullptr;          // behind everything the running job enqueued: what finish_slot waits for
     };
     std::vector<Slot> slots;
+    std::vector<hipStream_t> lanes;
+    int device = 0;
     uint64_t next = 0;
     int width = 0, height = 0;
     std::string err;
@@ -46,7 +52,7 @@ int ctx_fail(hsflow_pipeline *pl, hsflow_ctx *ctx, int code, const char *what)
     return pfail(pl, code, std::string(what) + ": " + hsflow_last_error(ctx));
 }
 
-// The launch shape for a pair whose caller left everything to the planner, when three or more slots share the chip and the
+// The launch shape for a pair whose caller left everything to the planner, when three or more lanes (streams) share the chip and the
 // frame is small: the planner shapes a solve for its own latency -- a 600x480 frame is cut into 210 tiles of 88x16 so
 // that every CU gets one, at five times the halo arithmetic -- but with the other slots' solves running beside it the
 // chip is full anyway and what counts is the CU-time a solve costs: few large tiles (strip kernel, 20 sweeps per launch,
@@ -59,7 +65,7 @@ hsflow_params stream_shape(const hsflow_pipeline *pl, const hsflow_params &in)
     static const bool off = getenv("HSFLOW_PIPELINE_AUTO_SHAPE") && atoi(getenv("HSFLOW_PIPELINE_AUTO_SHAPE")) == 0;
     hsflow_params p = in;
     const long long px = (long long)pl->width * pl->height;
-    if (off || pl->slots.size() < 3 || p.struct_size != sizeof(hsflow_params) || p.mode != HSFLOW_MODE_CV || p.kernel != HSFLOW_KERNEL_AUTO ||
+    if (off || pl->lanes.size() < 3 || p.struct_size != sizeof(hsflow_params) || p.mode != HSFLOW_MODE_CV || p.kernel != HSFLOW_KERNEL_AUTO ||
         p.fuse_steps || p.strip_rows || p.threads || p.tile_w || p.tile_h || !(p.term_type & HSFLOW_TERM_ITER) || p.max_iter <= 0 ||
         px > 1500000LL || pl->width < 256 || pl->height < 80)
         return p;
@@ -78,8 +84,20 @@ int finish_slot(hsflow_pipeline *pl, hsflow_pipeline::Slot &s)
 {
     if (!s.busy) return HSFLOW_OK;
     s.busy = false; // also on failure: the job is over either way
-    int st = hsflow_synchronize(s.ctx); // also settles the early-stop check of an ITER|EPS solve
-    if (st) return ctx_fail(pl, s.ctx, st, "hsflow_synchronize");
+    // Only THIS job is waited for -- the event behind what it enqueued -- not the jobs other slots have queued on the same
+    // lane since; hsflow_wait_solve then settles the early-stop check of an ITER|EPS solve (its witness words were reduced
+    // in-stream, before the event).
+    // A device-resident job carries no event at all (an event record between the solves of a stream costs the stream 6 %,
+    // tools/event_cost.py): the marker kernel behind its solve is polled (hsflow_wait_solve).  A host-memory job's
+    // downloads come after the solve, so the event behind them is what says "done".
+    // (a slot that has its lane to itself -- hsflow_pipeline_create -- simply waits for its stream, no event needed)
+    if (s.u) {
+        const bool own_lane = pl->lanes.size() == pl->slots.size();
+        if (hipSetDevice(pl->device) != hipSuccess || (own_lane ? hipStreamSynchronize(s.stream) : hipEventSynchronize(s.ev)) != hipSuccess)
+            return pfail(pl, HSFLOW_E_DEVICE, "waiting for the slot's downloads failed");
+    }
+    int st = hsflow_wait_solve(s.ctx);
+    if (st) return ctx_fail(pl, s.ctx, st, "hsflow_wait_solve");
     hsflow_info info;
     info.struct_size = sizeof(info);
     // (without last_eps: an asynchronous ITER|EPS solve measures it only on demand -- hsflow_pipeline_info)
@@ -97,16 +115,38 @@ extern "C" {
 
 int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int height, int depth)
 {
+    return hsflow_pipeline_create_lanes(out, device, width, height, depth, depth);
+}
+
+int hsflow_pipeline_create_lanes(hsflow_pipeline **out, int device, int width, int height, int depth, int lanes)
+{
     if (!out) return pfail(nullptr, HSFLOW_E_ARG, "out is null");
     *out = nullptr;
     if (depth < 1 || depth > 16) return pfail(nullptr, HSFLOW_E_ARG, "depth must be 1..16");
+    if (lanes < 1 || lanes > depth) return pfail(nullptr, HSFLOW_E_ARG, "lanes must be 1..depth");
     hsflow_pipeline *pl = new (std::nothrow) hsflow_pipeline();
     if (!pl) return pfail(nullptr, HSFLOW_E_OOM, "host allocation failed");
     pl->slots.resize((size_t)depth);
     pl->width = width;
     pl->height = height;
+    pl->device = device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        hsflow_pipeline_destroy(pl);
+        return pfail(nullptr, HSFLOW_E_ARG, "hsflow_create: device ordinal out of range");
+    }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); hsflow_pipeline_destroy(pl); return pfail(nullptr, HSFLOW_E_DEVICE, "hipSetDevice failed"); }
+    for (int l = 0; l < lanes; l++) {
+        hipStream_t st_ = nullptr;
+        if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) { hsflow_pipeline_destroy(pl); return pfail(nullptr, HSFLOW_E_DEVICE, "hipStreamCreateWithFlags failed"); }
+        pl->lanes.push_back(st_);
+    }
+    int k_ = 0;
     for (auto &s : pl->slots) {
-        const int st = hsflow_create(&s.ctx, device, width, height, 1, nullptr, /*own_stream*/ 1);
+        s.stream = pl->lanes[(size_t)(k_++ % lanes)];
+        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { hsflow_pipeline_destroy(pl); return pfail(nullptr, HSFLOW_E_DEVICE, "hipEventCreateWithFlags failed"); }
+        const int st = hsflow_create(&s.ctx, device, width, height, 1, (void *)s.stream, /*own_stream*/ 0);
         if (st) {
             g_pipeline_create_error = std::string("hsflow_create: ") + hsflow_last_error(nullptr);
             hsflow_pipeline_destroy(pl);
@@ -130,7 +170,12 @@ int hsflow_pipeline_create(hsflow_pipeline **out, int device, int width, int hei
 int hsflow_pipeline_destroy(hsflow_pipeline *pl)
 {
     if (!pl) return HSFLOW_OK;
-    for (auto &s : pl->slots) hsflow_destroy(s.ctx); // destroy synchronises the slot's stream
+    if (!pl->lanes.empty()) hipSetDevice(pl->device);
+    for (auto &s : pl->slots) {
+        hsflow_destroy(s.ctx); // destroy synchronises the slot's stream
+        if (s.ev) hipEventDestroy(s.ev);
+    }
+    for (hipStream_t l : pl->lanes) hipStreamDestroy(l);
     delete pl;
     return HSFLOW_OK;
 }
@@ -170,6 +215,10 @@ int hsflow_pipeline_submit_ex(hsflow_pipeline *pl, int format, const uint8_t *pr
     if ((st = hsflow_get_flow_async(s.ctx, 0, u, us, v, vs))) {
         hsflow_synchronize(s.ctx);
         return ctx_fail(pl, s.ctx, st, "hsflow_get_flow_async");
+    }
+    if (pl->lanes.size() != pl->slots.size() && hipEventRecord(s.ev, s.stream) != hipSuccess) { // (behind the downloads; see finish_slot)
+        hsflow_synchronize(s.ctx);
+        return pfail(pl, HSFLOW_E_DEVICE, "hipEventRecord failed");
     }
     s.busy = true;
     s.ticket = pl->next;

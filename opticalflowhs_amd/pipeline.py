@@ -39,11 +39,14 @@ class _DeviceView(object):
 class PairPipeline(object):
     """`depth` single-pair contexts used round-robin.  Termination: ITER (default) or ITER|EPS."""
 
-    def __init__(self, width, height, depth=4, device=0):
+    def __init__(self, width, height, depth=4, device=0, lanes=None):
+        """lanes: streams the slots are spread over (default: one per slot -- host-memory pairs; device-resident streams
+        want 2 lanes with 4 - 8 slots, hsflow_pipeline_create_lanes)."""
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         self.width, self.height = int(width), int(height)
-        st = self._lib.hsflow_pipeline_create(ctypes.byref(self._h), int(device), self.width, self.height, int(depth))
+        st = self._lib.hsflow_pipeline_create_lanes(ctypes.byref(self._h), int(device), self.width, self.height, int(depth),
+                                                    int(depth if lanes is None else lanes))
         if st:
             self._h = None
             raise HsflowError(st, (self._lib.hsflow_pipeline_last_error(None) or b"").decode())

@@ -36,7 +36,7 @@ def test_bench_single_gpu_line(gpu_ok):
     # OpticalFlowOpenCV.cpp:91-95) through the device-resident pair pipeline; ITER through the same loop beside it; no early
     # stop on these pairs; every pair's own early-stop check is settled (nothing carried over between steps)
     assert d["config"]["termination"].startswith("ITER|EPS") and d["config"]["iterations_done"] == 100 and d["config"]["eps_rerun"] == 0
-    assert d["config"]["loop"] == "stream" and d["config"]["call"].startswith("hsflow_pipeline_submit_device") and "own check" in d["config"]["eps_check"]
+    assert d["config"]["loop"] == "stream" and d["config"]["call"].startswith("hsflow_pipeline_submit_device, 6 slots on 2 streams") and "own check" in d["config"]["eps_check"]
     assert d["other_termination"]["termination"] == "ITER" and d["other_termination"]["ms_per_step"] > 0
     assert d["fresh_frames"]["is_the_headline"] is True and d["fresh_frames"]["ms_per_step"] == d["ms_per_step"]
     # rounds 1-2's loop (the same pair again and again on one context) beside it; the stream must not be slower than 1.03 x that ITER figure

@@ -58,10 +58,10 @@ for tt, name in ((hs.TERM_ITER, "ITER"), (hs.TERM_ITER | hs.TERM_EPS, "ITER|EPS"
             ctx.synchronize()
         print("%dx%d/%d %-8s one context, same pair every step: %.4f ms;  new pair every step (set_frames settles the owed check): %.4f ms"
               % (W, H, it, name, best(same), best(fresh_one_ctx)), flush=True)
-    for depth in (1, 2, 3, 4):
-        with hs.PairPipeline(W, H, depth=depth) as pl:
+    for depth, lanes in ((1, 1), (2, 2), (3, 3), (4, 4), (3, 2), (4, 2), (6, 2), (8, 2), (6, 3), (6, 1)):
+        with hs.PairPipeline(W, H, depth=depth, lanes=lanes) as pl:
             def fresh():
                 for k in range(args.steps):
                     pl.submit_device(seeds[k & 1][0], seeds[k & 1][1], params=p)
                 pl.drain()
-            print("   pipeline depth %d, new pair every step: %.4f ms" % (depth, best(fresh)), flush=True)
+            print("   pipeline of %d slots on %d stream(s), new pair every step: %.4f ms" % (depth, lanes, best(fresh)), flush=True)

@@ -14,7 +14,7 @@ run python bench.py --steps 20 --warmup 5 --skip-cpu > "$OUT/bench_1080p_driver_
 run python bench.py --loop repeat --skip-cpu > "$OUT/bench_1080p_repeat_loop.json" 2>> "$OUT/err.txt" || exit 2
 run python bench.py --sync-solves --skip-cpu > "$OUT/bench_1080p_sync_solves.json" 2>> "$OUT/err.txt" || exit 2
 run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5 --skip-cpu > "$OUT/bench_4k.json" 2>> "$OUT/err.txt" || exit 3
-run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5 --skip-cpu --stream-depth 3 > "$OUT/bench_4k_depth3.json" 2>> "$OUT/err.txt" || exit 3
+run python bench.py --width 3840 --height 2160 --iters 200 --steps 50 --warmup 5 --skip-cpu --stream-lanes 3 > "$OUT/bench_4k_3lanes.json" 2>> "$OUT/err.txt" || exit 3
 { run python tools/fresh_frames.py; run python tools/fresh_frames.py --width 3840 --height 2160 --iters 200 --steps 60; } > "$OUT/fresh_frames.txt" 2>> "$OUT/err.txt" || exit 3
 { HSFLOW_DEBUG_STAMPS=/tmp/persist_stamps.txt run python tools/persist_check.py --reps 200 --fuse-steps 20 16; run python tools/persist_check.py --width 424 --height 240 --reps 200 --fuse-steps 20; } > "$OUT/persist.txt" 2>> "$OUT/err.txt" || exit 3
 run python tools/classic_stream.py > "$OUT/classic_stream.txt" 2>> "$OUT/err.txt" || exit 3
