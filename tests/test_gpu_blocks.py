@@ -119,3 +119,34 @@ def test_switches_do_not_change_a_bit_and_the_flow_view_is_the_flow(hs, gpu_ok):
             v = torch.as_tensor(_DeviceView(pv.value, (H, W), (sb.value, 4)), device="cuda").cpu().numpy()
             assert np.array_equal(u, ref[p][0]) and np.array_equal(v, ref[p][1])
         assert lib.hsflow_flow_view_device(ctx._h, 2, ctypes.byref(pu), ctypes.byref(pv), ctypes.byref(sb)) == hs._lib.E_ARG
+
+
+def test_cached_plans_do_not_carry_a_callers_flags(hs, gpu_ok):
+    """A context plans once per parameter set (the planner's sweep costs tens of microseconds per solve); what does not enter the
+    plan -- use_previous, reuse_derivatives, use_graph -- must still be honoured on every call."""
+    W, H, it = 700, 300, 24
+    A, B = synth.translating_pair(W, H, seed=17)
+    A2, B2 = synth.translating_pair(W, H, seed=18)
+
+    def fresh(frames, steps):
+        with hs.HSFlow(W, H, 1, own_stream=True) as c:
+            c.set_frames(*frames)
+            for kw in steps:
+                c.solve(lam=0.9, max_iter=it, term_type=ITER, **kw)
+            return c.flow()
+
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        ctx.set_frames(A, B)
+        seq = [dict(), dict(use_previous=True), dict(use_previous=True, use_graph=True), dict(), dict(use_graph=True), dict(use_previous=True, reuse_derivatives=True)]
+        for k in range(len(seq)):
+            ctx.solve(lam=0.9, max_iter=it, term_type=ITER, **seq[k])
+            u, v = ctx.flow()
+            j = max(i for i in range(k + 1) if not seq[i].get("use_previous"))   # the last cold start
+            uo, vo = fresh((A, B), seq[j:k + 1])
+            assert np.array_equal(u, uo) and np.array_equal(v, vo), k
+        # new frames, same parameters: reuse_derivatives must not be inherited from the cached call
+        ctx.set_frames(A2, B2)
+        ctx.solve(lam=0.9, max_iter=it, term_type=ITER)
+        u, v = ctx.flow()
+        uo, vo = fresh((A2, B2), [dict()])
+        assert np.array_equal(u, uo) and np.array_equal(v, vo)
