@@ -25,6 +25,7 @@ ap.add_argument("--T", type=int, nargs="*", default=[6, 8, 10, 12, 14, 16, 20])
 ap.add_argument("--R", type=int, nargs="*", default=[3, 4, 5])
 ap.add_argument("--NW", type=int, nargs="*", default=[6, 8, 10, 12, 16])
 ap.add_argument("--fold", action="store_true")
+ap.add_argument("--lanes", type=int, default=0, help="streams the slots share (0: one per slot)")
 ap.add_argument("--term", choices=["iter", "itereps"], default="itereps")
 args = ap.parse_args()
 W, H, it = args.width, args.height, args.iters
@@ -41,7 +42,7 @@ print("name,depth,ms_per_pair,mpix_iter_per_s,tiles,threads,rows,T,tile_w,tile_h
 def run(name, depth, **kw):
     p = hs.make_params(lam=1.0, max_iter=it, term_type=tt, epsilon=eps6, use_graph=True, **kw)
     try:
-        with hs.PairPipeline(W, H, depth=depth) as pl:
+        with hs.PairPipeline(W, H, depth=depth, lanes=args.lanes or None) as pl:
             def go(n):
                 for k in range(n):
                     pl.submit_device(seeds[k & 1][0], seeds[k & 1][1], params=p)
