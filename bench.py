@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--c4-pairs", type=int, default=512, help="pairs of config C4 over all ranks")
     ap.add_argument("--c4-pool", type=int, default=8, help="distinct synthetic pairs per rank that the C4 submissions cycle through")
     ap.add_argument("--c5", choices=["auto", "on", "off"], default="auto", help="config C5: one frame in row slabs with halo exchange")
+    ap.add_argument("--side-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the C4 / C5 measurements may take together before the line is printed without them")
+    ap.add_argument("--debug-hang", choices=["", "c4", "c5"], default="", help=argparse.SUPPRESS)  # tests: a side measurement that never returns
     ap.add_argument("--c5-size", type=int, default=16384)
     ap.add_argument("--c5-iters", type=int, default=500)
     ap.add_argument("--c5-halo", type=int, default=16)
@@ -733,17 +736,42 @@ def main():
     # --- multi-GPU configs of BASELINE.json beside the headline ---------------------------------------------
     want_c4 = args.c4 == "on" or (args.c4 == "auto" and world > 1)
     want_c5 = args.c5 == "on" or (args.c5 == "auto" and world > 1)
-    # (a failure in one of these must not cost the headline: it is recorded under the key instead)
+    # (a failure in one of these must not cost the headline: it is recorded under the key instead -- and neither must a
+    # hang: the exchange of C5 is the one part of this file that has never run over RCCL on real peers, so a watchdog on
+    # every rank ends the run after --side-timeout seconds; rank 0 prints the line with what it has first)
+    watchdog = None
+    if world > 1 and (want_c4 or want_c5) and args.side_timeout > 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                late = dict(out)
+                for k, want in (("c4_pipeline", want_c4), ("c5_slab", want_c5)):
+                    if want and k not in late:
+                        late[k] = {"error": "no result within --side-timeout %.0f s: abandoned, the headline stands" % args.side_timeout}
+                sys.stdout.write(json.dumps(late) + "\n")
+                sys.stdout.flush()
+            os._exit(0)  # (a rank stuck inside a collective cannot be unwound; the process group dies with the process)
+
+        watchdog = threading.Timer(args.side_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if want_c4:
+        if args.debug_hang == "c4":
+            time.sleep(1e6)
         try:
             out["c4_pipeline"] = run_c4(args, hs, synth, dist, world, rank, local_rank, barrier, reduce_max)
         except Exception as e:  # noqa: BLE001 -- reported in the line, the run goes on
             out["c4_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if want_c5:
+        if args.debug_hang == "c5":
+            time.sleep(1e6)
         try:
             out["c5_slab"] = run_c5(args, hs, synth, torch, dist, world, rank, local_rank, backend, barrier, reduce_max)
         except Exception as e:  # noqa: BLE001
             out["c5_slab"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank == 0 and world == 1 and not args.no_side and args.kernel == "auto" and (W, H, iters) == (1920, 1080, 100):
         try:
@@ -777,9 +805,15 @@ def main():
                                          "sample": "%d solves of the same pair, OpenMP row-parallel form, %.1f s" % (n2, t2)}
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        import threading
+        bye = threading.Timer(30.0, lambda: os._exit(0))  # a peer that gave up (above) never reaches this barrier: the line is out, leave
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":

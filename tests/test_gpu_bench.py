@@ -110,6 +110,20 @@ def test_bench_gpus_2_launches_its_own_ranks(gpu_ok):
         assert k in d, k
 
 
+def test_bench_ranks_give_up_on_a_hung_side_measurement(gpu_ok):
+    """A C5 exchange that never returns (it has never run over RCCL on real peers) must not cost the SCALE record its
+    headline: after --side-timeout every rank ends itself, rank 0 having printed the line with the error under the key."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSFLOW_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-side",
+                        "--c4-pairs", "8", "--c5-size", "1024", "--c5-iters", "20", "--side-timeout", "20", "--debug-hang", "c5"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["c4_pipeline"]["value"] > 0
+    assert "abandoned" in d["c5_slab"]["error"]
+
+
 @pytest.mark.parametrize("extra", [[], ["--overlap"]])
 def test_slab_two_ranks_rehearsal_is_bit_identical(gpu_ok, extra):
     """tools/bench_slab.py with two ranks sharing the card (gloo, halo rows staged through the host): the
