@@ -111,6 +111,7 @@ struct hsflow_ctx {
     // hsflow_set_async_reduce: every asynchronous solve is followed by k_mark_done; the host waits for a solve by polling the
     // page-locked word (hsflow_wait_solve) instead of waiting for the stream
     unsigned *dSeq = nullptr, *hMark = nullptr, *hMarkDev = nullptr;
+    float *dZero = nullptr; // one row of zeros (P floats): stands in for u and v in strip / fold launches that start from zero flow
     unsigned mark_issued = 0;       // markers enqueued so far = the value the last one will write
     bool last_marked = false;       // the last solve was followed by a marker
     bool async_reduce = false;      // hsflow_set_async_reduce

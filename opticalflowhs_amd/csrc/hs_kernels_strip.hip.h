@@ -66,7 +66,7 @@ struct StripGeom {
     int CW, CH;         // core = (256 - 2*HX) x (NW*R - 2*T)
     int NW;             // wavefronts per workgroup
     int tiles_x, tiles_y;
-    int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
+    int zero_in;        // incoming flow is identically zero: u_in = v_in = ONE row of zeros (at least P floats), read with pitch 0
     int org;            // frame row of this context's row 0, modulo 2 (row slabs; checkerboard phase of update_cv)
     int ey0, ey1;       // rows [ey0, ey1) of the context whose changes count for Eps and the witness (hsflow_set_eps_rows: a row slab's
                         // owned rows -- its halo rows repeat a neighbour's, stale towards the slab's edge); the strip kernel only
@@ -387,49 +387,19 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const long long off = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P + xg;
-        lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (zero_in: u_in = v_in = one row of zeros, see StripGeom -- the loads stay unconditional: under a branch per
+        // row the compiler waits for each row's two loads before it issues the next row's)
+        const long long off_uv = g.zero_in ? (long long)xg : off;
         lc[r] = make_uint4(0u, 0u, 0u, 0u);
-        if (!g.zero_in) {
-            lu[r] = *(const float4 *)(u_in + off);
-            lv[r] = *(const float4 *)(v_in + off);
-        }
+        lu[r] = *(const float4 *)(u_in + off_uv);
+        lv[r] = *(const float4 *)(v_in + off_uv);
         if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
     }
-    if (xedge) { // workgroup-uniform
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (xrev) {
-                lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
-                lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
-                lc[r] = make_uint4(lc[r].w, lc[r].z, lc[r].y, lc[r].x);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(slow) != 0) { // wave-uniform: rare (W % 4 != 0, or an image narrower than the halo)
-            if (slow) {
-                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
-                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const long long row = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P;
-                    if (!g.zero_in) {
-                        const float *uv = u_in + row, *vv = v_in + row;
-                        lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
-                        lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
-                    }
-                    if (!DERIV) {
-                        const uint32_t *cv = coef + row;
-                        lc[r] = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
-                    }
-                }
-            }
-        }
-    }
-    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, rev ? y0 + R - 1 : y0, rev ? -1 : 1, xin, lc);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
+    // The lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows); the packed derivative
+    // word becomes the three coefficients of the update (sweep_coefs: one v_rsq per pixel).
+    auto unpack_row = [&](const int r) __attribute__((always_inline)) {
         const float4 lu_ = lu[r], lv_ = lv[r];
         const uint4 cw = lc[r];
-        // the lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows)
         constexpr int iPx = 0, iPy = 3, iQx = 1, iQy = 2;
         const float lu4[4] = {lu_.x, lu_.y, lu_.z, lu_.w}, lv4[4] = {lv_.x, lv_.y, lv_.z, lv_.w};
         uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
@@ -441,6 +411,55 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         cf[r].alP = f2{al[iPx], al[iPy]}; cf[r].alQ = f2{al[iQx], al[iQy]};
         cf[r].beP = f2{be[iPx], be[iPy]}; cf[r].beQ = f2{be[iQx], be[iQy]};
         cf[r].gaP = f2{ga[iPx], ga[iPy]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[iQx], ga[iQy]} * (HS_SCALED ? 4.0f : 1.0f);
+    };
+    // The rows are unpacked as they arrive, straight behind the loads with no branch in between (a third of the launch's
+    // set-up is this arithmetic: behind the side tiles' fix-ups the compiler waits for ALL loads first).  A mirrored
+    // group arrives reversed: (p0, p1, p2, p3) -> (p3, p2, p1, p0) is a swap of the halves of every register pair.
+    if constexpr (!DERIV) {
+#pragma unroll
+        for (int r = 0; r < R; r++) unpack_row(r);
+    }
+    if (xedge) { // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if constexpr (DERIV) { // (not unpacked yet; the derivative words come in lane order from strip_derive)
+                if (xrev) {
+                    lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
+                    lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
+                }
+            } else {
+                uP[r] = xrev ? f2_swap(uP[r]) : uP[r]; uQ[r] = xrev ? f2_swap(uQ[r]) : uQ[r];
+                vP[r] = xrev ? f2_swap(vP[r]) : vP[r]; vQ[r] = xrev ? f2_swap(vQ[r]) : vQ[r];
+                cf[r].alP = xrev ? f2_swap(cf[r].alP) : cf[r].alP; cf[r].alQ = xrev ? f2_swap(cf[r].alQ) : cf[r].alQ;
+                cf[r].beP = xrev ? f2_swap(cf[r].beP) : cf[r].beP; cf[r].beQ = xrev ? f2_swap(cf[r].beQ) : cf[r].beQ;
+                cf[r].gaP = xrev ? f2_swap(cf[r].gaP) : cf[r].gaP; cf[r].gaQ = xrev ? f2_swap(cf[r].gaQ) : cf[r].gaQ;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) { // wave-uniform: rare (W % 4 != 0, or an image narrower than the halo)
+            if (slow) {
+                const int xa = mirror_index(x0, g.W), xb = mirror_index(x0 + 1, g.W),
+                          xc = mirror_index(x0 + 2, g.W), xd = mirror_index(x0 + 3, g.W);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const long long row = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P;
+                    {
+                        const float *uv = u_in + (g.zero_in ? 0 : row), *vv = v_in + (g.zero_in ? 0 : row);
+                        lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
+                        lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
+                    }
+                    if constexpr (!DERIV) {
+                        const uint32_t *cv = coef + row;
+                        lc[r] = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                        unpack_row(r);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (DERIV) {
+        strip_derive<R>(fA, fB, g, base, x0, rev ? y0 + R - 1 : y0, rev ? -1 : 1, xin, lc);
+#pragma unroll
+        for (int r = 0; r < R; r++) unpack_row(r);
     }
     // core membership (for the store and for Eps): rows as a bit mask, lanes as a flag
     unsigned rowcore = 0;
@@ -982,12 +1001,10 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
     for (int r = 0; r < R; r++) {
         const int y = yb + (lower ? 2 * R - 1 - r : r);
         const long long off = base + (long long)mirror_index(y, g.H) * g.P + xg;
-        lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const long long off_uv = g.zero_in ? (long long)xg : off; // (zero_in: one row of zeros, k_jacobi_strip)
         lc[r] = make_uint4(0u, 0u, 0u, 0u);
-        if (!g.zero_in) {
-            lu[r] = *(const float4 *)(u_in + off);
-            lv[r] = *(const float4 *)(v_in + off);
-        }
+        lu[r] = *(const float4 *)(u_in + off_uv);
+        lv[r] = *(const float4 *)(v_in + off_uv);
         if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
     }
     if (side) { // workgroup-uniform
@@ -1007,8 +1024,8 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                 for (int r = 0; r < R; r++) {
                     const int y = yb + (lower ? 2 * R - 1 - r : r);
                     const long long row = base + (long long)mirror_index(y, g.H) * g.P;
-                    if (!g.zero_in) {
-                        const float *uv = u_in + row, *vv = v_in + row;
+                    {
+                        const float *uv = u_in + (g.zero_in ? 0 : row), *vv = v_in + (g.zero_in ? 0 : row);
                         lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
                         lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
                     }

@@ -393,6 +393,7 @@ hipError_t launch_strip_te(const hsflow_ctx *c, const StripPlan &p, const float 
         configured[c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
+    if (p.g.zero_in) ui = vi = c->dZero; // flow from zero: one row of zeros stands in for both planes (StripGeom::zero_in)
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi,
                        uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
@@ -453,6 +454,7 @@ hipError_t launch_strip_deriv_te(const hsflow_ctx *c, const StripPlan &p, const 
         configured[c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
+    if (p.g.zero_in) ui = vi = c->dZero;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi,
                        uo, vo, p.g, coeff, c->epsPtr, c->epsStride, p.tiles <= 65536 ? c->dStamps : nullptr, c->epsThr);
     return hipGetLastError();
@@ -529,6 +531,7 @@ hipError_t launch_persist_te(hsflow_ctx *c, const StripPlan &p, const hsk::Persi
     }
     if (resident[dv].load() < 1) return hipErrorCooperativeLaunchTooLarge;
     if (configure_only) return hipSuccess;
+    if (p.g.zero_in) ui = vi = c->dZero;
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dA, c->dB, c->dCoef, ui, vi, p.g, coeff,
                        c->epsPtr, c->epsStride, p.tiles <= 8192 ? c->dStamps : nullptr, c->epsThr, pa);
     return hipGetLastError();

@@ -146,6 +146,8 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     }
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
     c->epsPtr = c->dEps;
+    HS_TRY(hipMalloc((void **)&c->dZero, ((size_t)c->P + 64) * sizeof(float)));
+    HS_TRY(hipMemset(c->dZero, 0, ((size_t)c->P + 64) * sizeof(float)));
     {
         int ncu = 0;
         HS_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -214,6 +216,7 @@ int hsflow_destroy(hsflow_ctx *c)
     hipFree(c->dEpsTiles); hipFree(c->dUb); hipFree(c->dVb);
     hipFree(c->dUp); hipFree(c->dVp); hipFree(c->dFlags);
     hipFree(c->dSeq);
+    hipFree(c->dZero);
     if (c->hMark) hipHostFree(c->hMark);
     if (c->hErr) hipHostFree(c->hErr);
     if (c->counted) g_live_ctx[c->device & 63]--;
