@@ -35,7 +35,7 @@ struct ClassicStripGeom {
     int NW;             // wavefronts per workgroup
     int tiles_x, tiles_y;
     int ylast;          // first region row of the LAST tile row (bottom-aligned: H - CH - TH; -TH if there is one tile row)
-    int zero_in;        // incoming flow is identically zero: do not read u_in / v_in
+    int zero_in;        // incoming flow is identically zero: u_in = v_in = ONE row of zeros (at least P floats), read with pitch 0
 };
 
 // The IEEE division t / den of Kernels.cl:85 with the denominator's share of the work done once per pixel.  This is the
@@ -137,11 +137,11 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const long long row = base + (long long)clampi(y0 + r, 0, g.H - 1) * g.P;
-        lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!g.zero_in) {
-            lu[r] = *(const float4 *)(u_in + row + xg);
-            lv[r] = *(const float4 *)(v_in + row + xg);
-        }
+        // (zero_in: u_in = v_in = ONE row of zeros, read with pitch 0 -- the loads stay unconditional: under a branch per
+        // row the compiler waits for each row's two loads before it issues the next row's, see k_jacobi_strip)
+        const long long row_uv = g.zero_in ? 0ll : row;
+        lu[r] = *(const float4 *)(u_in + row_uv + xg);
+        lv[r] = *(const float4 *)(v_in + row_uv + xg);
         lc[r] = *(const uint4 *)(coef + row + xg);
     }
     if (GHOST && __builtin_amdgcn_ballot_w64(slow) != 0) { // Tex2D clamp (Kernels.cl:2-9): columns right of W-1 read column W-1
@@ -151,9 +151,10 @@ __global__ __launch_bounds__(NTMAX) void k_classic_strip(const uint32_t *__restr
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const long long row = base + (long long)clampi(y0 + r, 0, g.H - 1) * g.P;
-                if (!g.zero_in) {
-                    lu[r] = make_float4(u_in[row + xa], u_in[row + xb], u_in[row + xc], u_in[row + xd]);
-                    lv[r] = make_float4(v_in[row + xa], v_in[row + xb], v_in[row + xc], v_in[row + xd]);
+                {
+                    const long long ru = g.zero_in ? 0ll : row;
+                    lu[r] = make_float4(u_in[ru + xa], u_in[ru + xb], u_in[ru + xc], u_in[ru + xd]);
+                    lv[r] = make_float4(v_in[ru + xa], v_in[ru + xb], v_in[ru + xc], v_in[ru + xd]);
                 }
                 lc[r] = make_uint4(coef[row + xa], coef[row + xb], coef[row + xc], coef[row + xd]);
             }

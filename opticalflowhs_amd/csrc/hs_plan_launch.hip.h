@@ -257,6 +257,7 @@ hipError_t launch_classic_strip_t(const hsflow_ctx *c, const ClassicStripPlan &p
         configured[ki][c->device & 63] = true;
     }
     if (configure_only) return hipSuccess;
+    if (p.g.zero_in) ui = vi = c->dZero; // (flow from zero: one row of zeros stands in for both planes)
     hipLaunchKernelGGL(kern, dim3(p.tiles), dim3(p.g.NW * 64), p.lds_bytes, c->stream, c->dCoef, ui, vi, uo, vo, p.g, alpha2);
     return hipGetLastError();
 }
