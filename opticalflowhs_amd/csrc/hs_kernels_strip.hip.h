@@ -391,9 +391,25 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         // row the compiler waits for each row's two loads before it issues the next row's)
         const long long off_uv = g.zero_in ? (long long)xg : off;
         lc[r] = make_uint4(0u, 0u, 0u, 0u);
-        lu[r] = *(const float4 *)(u_in + off_uv);
-        lv[r] = *(const float4 *)(v_in + off_uv);
-        if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
+        if constexpr (!DERIV) {
+            lu[r] = *(const float4 *)(u_in + off_uv);
+            lv[r] = *(const float4 *)(v_in + off_uv);
+            lc[r] = *(const uint4 *)(coef + off);
+        } else {
+            lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if constexpr (DERIV) {
+        // The launch with the derivative pass is nearly always the one that starts from zero flow: then it reads no flow at
+        // all and goes straight to the frames (strip_derive); otherwise ONE branch around all the rows' loads.
+        if (!g.zero_in) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const long long off = base + (long long)mirror_index(y0 + img_row(r), g.H) * g.P + xg;
+                lu[r] = *(const float4 *)(u_in + off);
+                lv[r] = *(const float4 *)(v_in + off);
+            }
+        }
     }
     // The lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows); the packed derivative
     // word becomes the three coefficients of the update (sweep_coefs: one v_rsq per pixel).
