@@ -132,6 +132,15 @@ __device__ __forceinline__ unsigned load_u32_sc1(const unsigned *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The lane number from the hardware, at the point of use (two instructions): a register holding it across the sweep loop
+// is one the R = 5 kernels do not have (the mask goes through an empty asm so that the optimiser cannot hoist the pair).
+__device__ __forceinline__ int hs_lane_now()
+{
+    unsigned m = ~0u;
+    asm volatile("" : "+s"(m));
+    return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
+}
+
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2_swap(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 // old - new of a sweep, in the NEW value's scale (HS_SCALED: the old one is a factor 4 behind)
@@ -488,6 +497,13 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     }
     const bool lanecore = (x0 >= 0) && (x0 < g.W) && (4 * lane >= g.HX) && (4 * lane < g.HX + g.CW);
     const int pr = g.W - 1 - x0; // image columns of this group: 0..min(pr,3)
+    // From here on the Eps / witness kernels read `lane` from the hardware where it is used (hs_lane_now): nothing below
+    // keeps it in a register, and with the three LDS addresses of a sweep formed from that one value the witness kernel
+    // no longer spills (it reloaded a coefficient pair in every sweep: ITER|EPS stream 0.1325 -> 0.1254 ms per pair).  The
+    // plain kernel has the registers and is 0.8 % faster with the lane number kept.
+    const int lane_kept = lane;
+    constexpr bool LANE_HW = EPS != 0 || PERSIST;
+#define lane (LANE_HW ? hs_lane_now() : lane_kept)
     unsigned epscore = 0; // the core rows that lie in the Eps window (wave-uniform; all of them unless hsflow_set_eps_rows narrowed it)
     if (EPS != 0) {
 #pragma unroll
@@ -542,7 +558,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
     } while (0)
 #define HS_PUBLISH(buf)                                                                            \
     do {                                                                                           \
-        float4 *exw = ex + ((size_t)((buf) * NW + w) * 4) * 64 + lane;                             \
+        float4 *exw = ex + ((size_t)((buf) * NW + w) * 4) * 64 + HS_LANE;                          \
         exw[0] = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y);                                  \
         exw[64] = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);                                 \
         exw[128] = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y);                \
@@ -606,8 +622,13 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);
         const float4 du4 = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y), dv4 = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);
 #else
-        const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane;
-        const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane;
+        // (The three LDS addresses of a sweep are formed from ONE register, the lane number behind a barrier the optimiser
+        // cannot see through: left alone it keeps three loop-invariant address registers alive across the sweep loop, which
+        // has none to spare -- the witness kernel then reloads a spilled coefficient pair in every sweep.)
+        const int lane_l = lane;
+#define HS_LANE lane_l
+        const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane_l;
+        const float4 *ed = ex + ((size_t)((s & 1) * NW + wd) * 4 + sd) * 64 + lane_l;
         // (Idle strips -- late sweeps, halo wavefronts -- still read and publish their edge rows.  Gating the reads makes the
         // register allocator spill inside the loop; gating only the publish costs two more branches per sweep than the
         // LDS traffic it saves: 0.1363 against 0.1353 ms per pair, round 3.)
@@ -709,6 +730,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         wit_cnt = wit_cnt0;
         if (stamps && ph == 0) pt_first = pt0 = __builtin_amdgcn_s_memtime();
     }
+#undef HS_LANE
+#define HS_LANE lane
     HS_PUBLISH(0);
     __syncthreads();
     if (PERSIST && stamps && ph > 0) { // (the reloaded rows are first used by the publish above: their latency belongs to the reload)
@@ -758,8 +781,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         // (the lane's column is worked out afresh from a copy of the lane number the optimiser cannot see through: kept
         // alive across the sweep loop it is one of the three registers the loop has no room for -- every spilled register
         // is 250 KB of scratch written and read per launch, which showed up as HBM writes: profiles/r03_traffic_by_kernel.json)
-        int lane_s = lane;
-        asm volatile("" : "+v"(lane_s));
+        const int lane_s = lane;
         const int x0s = bx * g.CW - g.HX + 4 * lane_s;
         if (lanecore) {
 #pragma unroll
@@ -783,8 +805,7 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         // The lane's column and where it reads its halo from are worked out afresh in every phase, from a copy of the
         // lane number the optimiser cannot see through: hoisted out of the phase loop they would be two more registers
         // alive across the sweep loop, which has none to spare (the sweep then reloads spilled coefficients).
-        int lane_x = lane;
-        asm volatile("" : "+v"(lane_x));
+        const int lane_x = lane;
         const int x0x = bx * g.CW - g.HX + 4 * lane_x;
         int xgx = x0x;
         bool xrevx = false;
@@ -880,6 +901,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
 #undef HS_ACT
 #undef HS_CROSS
 #undef HS_PUBLISH
+#undef HS_LANE
+#undef lane
     if (stamps && threadIdx.x == 0) {
         __builtin_amdgcn_s_waitcnt(0); // stores issued and acknowledged
         unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
@@ -1019,17 +1042,58 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
         const long long off = base + (long long)mirror_index(y, g.H) * g.P + xg;
         const long long off_uv = g.zero_in ? (long long)xg : off; // (zero_in: one row of zeros, k_jacobi_strip)
         lc[r] = make_uint4(0u, 0u, 0u, 0u);
-        lu[r] = *(const float4 *)(u_in + off_uv);
-        lv[r] = *(const float4 *)(v_in + off_uv);
-        if (!DERIV) lc[r] = *(const uint4 *)(coef + off);
+        if constexpr (!DERIV) {
+            lu[r] = *(const float4 *)(u_in + off_uv);
+            lv[r] = *(const float4 *)(v_in + off_uv);
+            lc[r] = *(const uint4 *)(coef + off);
+        } else {
+            lu[r] = lv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if constexpr (DERIV) { // (k_jacobi_strip: no flow loads for a solve from zero flow, one branch around them otherwise)
+        if (!g.zero_in) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int y = yb + (lower ? 2 * R - 1 - r : r);
+                const long long off = base + (long long)mirror_index(y, g.H) * g.P + xg;
+                lu[r] = *(const float4 *)(u_in + off);
+                lv[r] = *(const float4 *)(v_in + off);
+            }
+        }
+    }
+    // the lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows); rows are unpacked as they
+    // arrive, before the side tiles' fix-ups (k_jacobi_strip: a reversed group = the halves of every pair swapped)
+    auto unpack_row = [&](const int r) __attribute__((always_inline)) {
+        constexpr int iPx = 0, iPy = 3, iQx = 1, iQy = 2;
+        const float lu4[4] = {lu[r].x, lu[r].y, lu[r].z, lu[r].w}, lv4[4] = {lv[r].x, lv[r].y, lv[r].z, lv[r].w};
+        uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
+        vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
+        float al[4], be[4], ga[4];
+        const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
+#pragma unroll
+        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
+        cf[r].alP = f2{al[iPx], al[iPy]}; cf[r].alQ = f2{al[iQx], al[iQy]};
+        cf[r].beP = f2{be[iPx], be[iPy]}; cf[r].beQ = f2{be[iQx], be[iQy]};
+        cf[r].gaP = f2{ga[iPx], ga[iPy]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[iQx], ga[iQy]} * (HS_SCALED ? 4.0f : 1.0f);
+    };
+    if constexpr (!DERIV) {
+#pragma unroll
+        for (int r = 0; r < R; r++) unpack_row(r);
     }
     if (side) { // workgroup-uniform
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            if (rev) {
-                lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
-                lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
-                lc[r] = make_uint4(lc[r].w, lc[r].z, lc[r].y, lc[r].x);
+            if constexpr (DERIV) {
+                if (rev) {
+                    lu[r] = make_float4(lu[r].w, lu[r].z, lu[r].y, lu[r].x);
+                    lv[r] = make_float4(lv[r].w, lv[r].z, lv[r].y, lv[r].x);
+                }
+            } else {
+                uP[r] = rev ? f2_swap(uP[r]) : uP[r]; uQ[r] = rev ? f2_swap(uQ[r]) : uQ[r];
+                vP[r] = rev ? f2_swap(vP[r]) : vP[r]; vQ[r] = rev ? f2_swap(vQ[r]) : vQ[r];
+                cf[r].alP = rev ? f2_swap(cf[r].alP) : cf[r].alP; cf[r].alQ = rev ? f2_swap(cf[r].alQ) : cf[r].alQ;
+                cf[r].beP = rev ? f2_swap(cf[r].beP) : cf[r].beP; cf[r].beQ = rev ? f2_swap(cf[r].beQ) : cf[r].beQ;
+                cf[r].gaP = rev ? f2_swap(cf[r].gaP) : cf[r].gaP; cf[r].gaQ = rev ? f2_swap(cf[r].gaQ) : cf[r].gaQ;
             }
         }
         if (__builtin_amdgcn_ballot_w64(slow) != 0) { // wave-uniform, rare
@@ -1045,30 +1109,20 @@ __device__ __forceinline__ void fold_body(const uint32_t *__restrict__ coef,
                         lu[r] = make_float4(uv[xa], uv[xb], uv[xc], uv[xd]);
                         lv[r] = make_float4(vv[xa], vv[xb], vv[xc], vv[xd]);
                     }
-                    if (!DERIV) {
+                    if constexpr (!DERIV) {
                         const uint32_t *cv = coef + row;
                         lc[r] = make_uint4(cv[xa], cv[xb], cv[xc], cv[xd]);
+                        unpack_row(r);
                     }
                 }
             }
         }
     }
     // (the wave shifts in strip_derive cross the lane 31/32 seam like those of the sweep: region-edge columns)
-    if (DERIV) strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);
+    if constexpr (DERIV) {
+        strip_derive<R>(fA, fB, g, base, x0, lower ? yb + 2 * R - 1 : yb, lower ? -1 : 1, xin, lc);
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        // the lane's pixels p0..p3 go into the register pairs P = (p0, p3), Q = (p1, p2) (cross_rows)
-        constexpr int iPx = 0, iPy = 3, iQx = 1, iQy = 2;
-        const float lu4[4] = {lu[r].x, lu[r].y, lu[r].z, lu[r].w}, lv4[4] = {lv[r].x, lv[r].y, lv[r].z, lv[r].w};
-        uP[r] = f2{lu4[iPx], lu4[iPy]}; uQ[r] = f2{lu4[iQx], lu4[iQy]};
-        vP[r] = f2{lv4[iPx], lv4[iPy]}; vQ[r] = f2{lv4[iQx], lv4[iQy]};
-        float al[4], be[4], ga[4];
-        const uint32_t cc[4] = {lc[r].x, lc[r].y, lc[r].z, lc[r].w};
-#pragma unroll
-        for (int p = 0; p < 4; p++) sweep_coefs(cc[p], ilambda, al[p], be[p], ga[p]);
-        cf[r].alP = f2{al[iPx], al[iPy]}; cf[r].alQ = f2{al[iQx], al[iQy]};
-        cf[r].beP = f2{be[iPx], be[iPy]}; cf[r].beQ = f2{be[iQx], be[iQy]};
-        cf[r].gaP = f2{ga[iPx], ga[iPy]} * (HS_SCALED ? 4.0f : 1.0f); cf[r].gaQ = f2{ga[iQx], ga[iQy]} * (HS_SCALED ? 4.0f : 1.0f);
+        for (int r = 0; r < R; r++) unpack_row(r);
     }
     // core membership: per lane (the two halves hold different rows); skip distances: per wavefront
     unsigned rowcore = 0;

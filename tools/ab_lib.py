@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of one library build (HSFLOW_LIB_PATH) at 1080p / 100, ITER: one context back to back, and the two-slot stream.
-usage: HSFLOW_LIB_PATH=tools/bin/libhsflow_X.so python tools/ab_lib.py [label]"""
+usage: HSFLOW_LIB_PATH=tools/bin/libhsflow_X.so python tools/ab_lib.py [label [eps]]"""
 import os
 import sys
 import time
@@ -19,7 +19,11 @@ for sd in (1, 2):
     A, B = synth.translating_pair(W, H, seed=sd)
     seeds.append((torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()))
 torch.cuda.synchronize()
-p = hs.make_params(lam=1.0, max_iter=it, term_type=hs.TERM_ITER, kernel=hs.KERNEL_STRIP, use_graph=True)
+if "eps" in sys.argv[2:]:  # the witness kernels: ITER|EPS with an epsilon no sweep undercuts
+    p = hs.make_params(lam=1.0, max_iter=it, term_type=hs.TERM_ITER | hs.TERM_EPS, epsilon=float(np.float32(1e-6)), kernel=hs.KERNEL_STRIP, use_graph=True)
+    label += " ITER|EPS"
+else:
+    p = hs.make_params(lam=1.0, max_iter=it, term_type=hs.TERM_ITER, kernel=hs.KERNEL_STRIP, use_graph=True)
 with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
     ctx.set_frames(seeds[0][0], seeds[0][1])
     for _ in range(100):
