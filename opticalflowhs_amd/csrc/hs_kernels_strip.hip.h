@@ -622,9 +622,10 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         const float4 hu4 = make_float4(uP[0].x, uP[0].y, uQ[0].x, uQ[0].y), hv4 = make_float4(vP[0].x, vP[0].y, vQ[0].x, vQ[0].y);
         const float4 du4 = make_float4(uP[R - 1].x, uP[R - 1].y, uQ[R - 1].x, uQ[R - 1].y), dv4 = make_float4(vP[R - 1].x, vP[R - 1].y, vQ[R - 1].x, vQ[R - 1].y);
 #else
-        // (The three LDS addresses of a sweep are formed from ONE register, the lane number behind a barrier the optimiser
-        // cannot see through: left alone it keeps three loop-invariant address registers alive across the sweep loop, which
-        // has none to spare -- the witness kernel then reloads a spilled coefficient pair in every sweep.)
+        // (Eps / witness kernels: the three LDS addresses of a sweep are formed from ONE value, the lane number as the
+        // hardware gives it at this point (hs_lane_now): left alone the compiler keeps three loop-invariant address
+        // registers alive across the sweep loop, which has none to spare -- the witness kernel then reloaded a spilled
+        // coefficient pair in every sweep.)
         const int lane_l = lane;
 #define HS_LANE lane_l
         const float4 *eu = ex + ((size_t)((s & 1) * NW + wu) * 4 + su) * 64 + lane_l;
@@ -781,7 +782,8 @@ __device__ __forceinline__ void strip_body(const uint32_t *__restrict__ coef,
         // (the lane's column is worked out afresh from a copy of the lane number the optimiser cannot see through: kept
         // alive across the sweep loop it is one of the three registers the loop has no room for -- every spilled register
         // is 250 KB of scratch written and read per launch, which showed up as HBM writes: profiles/r03_traffic_by_kernel.json)
-        const int lane_s = lane;
+        int lane_s = lane;
+        if constexpr (!LANE_HW) asm volatile("" : "+v"(lane_s)); // (the kept lane number: a copy the optimiser cannot see through)
         const int x0s = bx * g.CW - g.HX + 4 * lane_s;
         if (lanecore) {
 #pragma unroll
