@@ -150,3 +150,36 @@ def test_cached_plans_do_not_carry_a_callers_flags(hs, gpu_ok):
         u, v = ctx.flow()
         uo, vo = fresh((A2, B2), [dict()])
         assert np.array_equal(u, uo) and np.array_equal(v, vo)
+
+
+@pytest.mark.parametrize("shape", [(1920, 1080), (600, 480), (333, 150), (258, 81)])
+def test_a_solve_from_zero_flow_equals_a_warm_start_from_zeroed_planes(hs, gpu_ok, shape):
+    """A solve from zero flow hands the strip / fold / classic strip kernels ONE row of zeros in place of the two flow
+    planes (StripGeom::zero_in, hsflow_ctx::dZero); a warm start (`use_previous`) from planes that were set to zero
+    reads the planes themselves: the same bits, with and without the derivative pass in the first launch, ITER and
+    ITER|EPS, and in the classic mode."""
+    import torch
+    W, H = shape
+    A, B = synth.translating_pair(W, H, seed=11)
+    z = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    cases = [dict(kernel=hs.KERNEL_STRIP), dict(kernel=hs.KERNEL_FOLD), dict(kernel=hs.KERNEL_AUTO),
+             dict(kernel=hs.KERNEL_STRIP, reuse_derivatives=True), dict(mode=hs.MODE_CLASSIC, alpha=15.0)]
+    with hs.HSFlow(W, H, 1, own_stream=True) as ctx:
+        for kw in cases:
+            for tt in (ITER, ITER | EPS):
+                if kw.get("mode") == hs.MODE_CLASSIC and tt != ITER:
+                    continue
+                base = dict(lam=1.0, max_iter=37, term_type=tt, epsilon=1e-9, use_graph=True)
+                base.update(kw)
+                try:
+                    ctx.set_frames(A, B)
+                    if base.get("reuse_derivatives"):
+                        ctx.solve(**dict(base, reuse_derivatives=False, max_iter=1))  # leaves the derivative plane behind
+                    ctx.solve(**base)
+                except hs.HsflowError:
+                    continue  # a shape this frame cannot take (e.g. the folded kernel on a sliver)
+                u0, v0 = ctx.flow()
+                ctx.set_flow_rows_from(z, z, 0, H)
+                ctx.solve(**dict(base, use_previous=True))
+                u1, v1 = ctx.flow()
+                assert np.array_equal(u0, u1) and np.array_equal(v0, v1), (shape, kw, tt)
