@@ -147,7 +147,6 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     HS_TRY(hipMalloc((void **)&c->dEps, kMaxFuse * sizeof(unsigned)));
     c->epsPtr = c->dEps;
     HS_TRY(hipMalloc((void **)&c->dZero, ((size_t)c->P + 64) * sizeof(float)));
-    HS_TRY(hipMemset(c->dZero, 0, ((size_t)c->P + 64) * sizeof(float)));
     {
         int ncu = 0;
         HS_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -155,6 +154,7 @@ int hsflow_create(hsflow_ctx **out, int device, int width, int height, int n_pai
     }
     if (getenv("HSFLOW_DEBUG_STAMPS")) HS_TRY(hipMalloc((void **)&c->dStamps, (size_t)kStampTiles * 8 * sizeof(unsigned long long)));
     // deterministic contents for padding columns and the initial flow
+    HS_TRY(hipMemsetAsync(c->dZero, 0, ((size_t)c->P + 64) * sizeof(float), c->stream));
     HS_TRY(hipMemsetAsync(c->dA, 0, px, c->stream));
     HS_TRY(hipMemsetAsync(c->dB, 0, px, c->stream));
     HS_TRY(hipMemsetAsync(c->dCoef, 0, px * sizeof(uint32_t), c->stream));
